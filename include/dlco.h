@@ -1,0 +1,191 @@
+/*
+ * dlco.h — C ABI of libdlco.so: the MI355X (gfx950) implementation of opencv-dlco's
+ * projection-learning hot path (pj-learn).
+ *
+ * The reference (cbalint13/opencv-dlco) has no plugin or FFI interface: the path is a
+ * monolithic main() (src/pj-learn.cpp:57-600) plus the free functions declared in
+ * include/trainer.hpp:43-64.  Each entry point below names the reference code it
+ * replaces; a maintainer's pj-learn main() would call them in the order shown in
+ * INTEGRATION.md.  Plain pointers and sizes only; every buffer is caller-owned and
+ * copied by the library unless a function says otherwise.  All functions return
+ * DLCO_OK (0) or a negative error code; dlco_last_error() gives the message.  A context
+ * is driven by one host thread; distinct contexts are independent.
+ *
+ * There is no CPU fallback: dlco_ctx_create fails when no gfx950 device is usable.
+ */
+#ifndef DLCO_H
+#define DLCO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLCO_OK            0
+#define DLCO_ERR_INVALID  -2   /* bad argument / wrong call order          */
+#define DLCO_ERR_HIP      -3   /* HIP runtime error (message has details)  */
+#define DLCO_ERR_NODEVICE -4   /* no usable gfx950 device                  */
+#define DLCO_ERR_NOCONV   -5   /* eigen tracker did not reach its tolerance */
+
+typedef struct dlco_ctx dlco_ctx;
+
+/* Hyper-parameters and shapes.  Defaults (dlco_cfg_default) are the reference's
+ * hard-coded values, src/pj-learn.cpp:89-96,225. */
+typedef struct dlco_cfg {
+    int32_t  F;          /* FeatDim: columns of "Distance"                 (:179) */
+    int32_t  N;          /* nDists: rows of "Distance"/"Label"             (:178) */
+    int32_t  B;          /* szBatch per class, GLOBAL over all ranks       (:93)  */
+    float    mu;         /* trace-norm weight                              (:89)  */
+    float    gamma;      /* RDA step parameter                             (:90)  */
+    uint64_t seed;       /* sampler RNG seed                               (:225) */
+    int32_t  device;     /* HIP device ordinal                             (:267) */
+    int32_t  rank;       /* data-parallel rank: owns batch slots [rank*B/world, (rank+1)*B/world) */
+    int32_t  world;      /* number of ranks (1 = the reference's single device)           */
+    float    eig_tol;    /* subspace tracker tolerance on c*|residual| / max e (default 2e-4) */
+    int32_t  eig_guard;  /* guard vectors kept beyond the positive eigenspace (default 32)  */
+    int32_t  eig_max_iter; /* filter+Rayleigh-Ritz iterations per step before giving up      */
+    int32_t  reserved[8];
+} dlco_cfg;
+
+void dlco_cfg_default(dlco_cfg *cfg);
+
+const char *dlco_version(void);
+/* Message of the last error on this thread (ctx may be NULL for create failures). */
+const char *dlco_last_error(const dlco_ctx *ctx);
+
+/* Allocates device state; replaces cuda::setDevice(0) and the Mat::zeros block,
+ * src/pj-learn.cpp:259-291. */
+int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg);
+void dlco_ctx_destroy(dlco_ctx *ctx);
+/* "Found GPU: <name>" line of the reference log, src/pj-learn.cpp:259-263. */
+int dlco_device_name(const dlco_ctx *ctx, char *buf, size_t cap, int *cc_major, int *cc_minor);
+
+/* Uploads Distance [N,F] row-major f32 and Label [N] u8 (1 = match, 0 = non-match) to HBM,
+ * builds IdxPos/IdxNeg, shuffles and splits them.  Replaces src/pj-learn.cpp:214-256,277-281. */
+int dlco_set_data(dlco_ctx *ctx, const float *dists_host, const uint8_t *labels_host);
+/* Same, but `dists_dev` already lives in device memory and is adopted, not copied
+ * (it must stay valid for the life of the context). */
+int dlco_set_data_device(dlco_ctx *ctx, const float *dists_dev, const uint8_t *labels_host);
+/* Bench helper (no reference counterpart: the Brown/Winder sets are not redistributable):
+ * fills the context's Distance matrix in HBM with d = U^T z + noise*eps clipped to [-1,1],
+ * label = 1 for even rows; U is [k,F] on the host. */
+int dlco_synth_data(dlco_ctx *ctx, const float *U_host, int32_t k, uint64_t seed,
+                    float sigma_pos, float sigma_neg, float noise);
+/* Copies `n` rows [row0, row0+n) of the device-resident Distance matrix back to the host. */
+int dlco_get_rows(dlco_ctx *ctx, int32_t row0, int32_t n, float *out_host);
+
+/* Pair indexing (bit-exact contract): shuffled index vectors and the 80/20 split,
+ * src/pj-learn.cpp:214-237.  pos/neg may be NULL to query sizes only. */
+int dlco_get_index(const dlco_ctx *ctx, int32_t *pos, int32_t *n_pos, int32_t *n_pos_trn,
+                   int32_t *neg, int32_t *n_neg, int32_t *n_neg_trn);
+
+/* One iteration of the training loop, src/pj-learn.cpp:305-490 (sampling, distances,
+ * violation counts, gradient, dual average, PSD projection).  dlco_steps runs n of them
+ * without host synchronisation beyond what the eigen tracker needs. */
+int dlco_step(dlco_ctx *ctx);
+int dlco_steps(dlco_ctx *ctx, int32_t n);
+
+/* The same iteration split at its two exchange points, for data-parallel runs (one
+ * process per GPU; the caller moves the buffers with RCCL between the phases):
+ *   dlco_step_begin  : sample the global batch, project the rank's own slots;
+ *                      fills the rank's slice of the distance buffer
+ *   -- all-gather DLCO_BUF_DIST (2*B floats) --
+ *   dlco_step_grad   : violation counts over the global batch, the rank's partial
+ *                      gradient P^T diag(rho) P - N^T diag(kappa) N into DLCO_BUF_GRAD
+ *   -- sum all-reduce DLCO_BUF_GRAD (F*F floats) --
+ *   dlco_step_finish : dual average, PSD projection (replicated on every rank)
+ * With world == 1 the three calls in sequence equal dlco_step. */
+int dlco_step_begin(dlco_ctx *ctx);
+int dlco_step_grad(dlco_ctx *ctx);
+int dlco_step_finish(dlco_ctx *ctx);
+
+#define DLCO_BUF_DIST   1   /* f32 [world][2*B/world]: rank g's slice holds the distances of its
+                               B/world positive slots, then of its B/world negative slots   */
+#define DLCO_BUF_GRAD   2   /* f32 [F*F]: this rank's dLoss partial                    */
+#define DLCO_BUF_DFAVG  3   /* f32 [F*F]: running dual average                         */
+#define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
+/* Device pointer and byte size of an exchange buffer (valid until ctx is destroyed). */
+int dlco_dev_buffer(dlco_ctx *ctx, int32_t which, void **dev_ptr, size_t *bytes);
+/* The HIP stream the context launches on (as void*), so callers can order collectives. */
+int dlco_stream(dlco_ctx *ctx, void **stream);
+int dlco_sync(dlco_ctx *ctx);
+
+/* Row ids (into Distance) of the last sampled batch and their squared distances
+ * (src/pj-learn.cpp:311-314, 346-363); rho/kappa = violation counts (:373-376). */
+int dlco_get_batch(const dlco_ctx *ctx, int32_t *pos_rows, int32_t *neg_rows,
+                   float *pos_dist, float *neg_dist, int32_t *rho, int32_t *kappa);
+
+/* State access.  Rank follows the reference: rows of W with a strictly positive
+ * eigenvalue; when there are none, *r = F and W is F*F zeros (src/pj-learn.cpp:481-490). */
+int dlco_get_t(const dlco_ctx *ctx, uint32_t *t);
+int dlco_get_W(dlco_ctx *ctx, float *W_host /* cap F*F */, int32_t *r);
+int dlco_get_A(dlco_ctx *ctx, float *A_host /* F*F: PSD-projected A = W^T W */);
+int dlco_get_dfavg(dlco_ctx *ctx, float *dfavg_host /* F*F */);
+/* Teacher forcing: overwrite t, dfAvg and W (W may be NULL with r = 0 for the zero start).
+ * The eigen tracker restarts from the given W's row space. */
+int dlco_set_state(dlco_ctx *ctx, uint32_t t, const float *dfavg_host, const float *W_host, int32_t r);
+
+/* Validation objective, src/pj-learn.cpp:501-527: loss_val = hinge sum over the
+ * validation positives x negatives / nPosVal / nNegVal, regul = mu * trace(A). */
+int dlco_validate(dlco_ctx *ctx, float *loss_val, float *regul, int32_t *rank);
+
+/* ComputePJStats (src/misc.cpp:266-333) on all N rows.  W_host == NULL uses the
+ * context's current W. */
+int dlco_stats(dlco_ctx *ctx, const float *W_host, int32_t r, int32_t *dim, float *fpr95, double *auc);
+
+/* ---- single operators, exposed for parity tests and for eval-fpr95 ------------------- */
+/* P1+P2: out[i] = || W x_{row_ids[i]} ||^2 over rows of the resident Distance matrix. */
+int dlco_project_sqdist(dlco_ctx *ctx, const int32_t *row_ids_host, int32_t n,
+                        const float *W_host, int32_t r, float *out_host);
+/* V1: rho_i = #{j : pd_i + 1 > nd_j}, kappa_j = #{i : pd_i + 1 > nd_j}. */
+int dlco_viol_counts(dlco_ctx *ctx, const float *pd_host, const float *nd_host, int32_t B,
+                     int32_t *rho_host, int32_t *kappa_host);
+/* Q1+U1: dfavg_out = alpha*dfavg_in + beta*(P^T diag(rho) P - N^T diag(kappa) N) with rows
+ * taken from the resident Distance matrix (fused SYRK + dual average). */
+int dlco_grad_rda(dlco_ctx *ctx, const int32_t *pos_rows_host, const int32_t *neg_rows_host,
+                  const int32_t *rho_host, const int32_t *kappa_host, int32_t B,
+                  float alpha, float beta, const float *dfavg_in_host, float *dfavg_out_host);
+/* E1+E2: PSD projection of A = -(sqrt(t+1)/gamma)(dfavg + mu I); returns W (rows ascending
+ * in eigenvalue, as LAPACK orders them) and optionally A+. */
+int dlco_psd_project(dlco_ctx *ctx, const float *dfavg_host, uint32_t t,
+                     float *W_host, int32_t *r, float *A_host /* may be NULL */);
+/* H1: sum_i sum_j max(pos_i + 1 - neg_j, 0)  (src/kernelop-opencv.cu:49-80). */
+int dlco_hinge_sum(dlco_ctx *ctx, const float *pos_host, int32_t n_pos,
+                   const float *neg_host, int32_t n_neg, double *out);
+/* S3+S4 on host arrays. */
+int dlco_roc_stats(dlco_ctx *ctx, const float *dist_host, const uint8_t *labels_host, int32_t n,
+                   float *fpr95, double *auc);
+
+/* ---- model selection and logging, src/pj-learn.cpp:492-587 ---------------------------- */
+typedef struct dlco_log_entry {
+    uint32_t t;
+    int32_t  is_best;      /* 1: "Best:" line + "Stat:" line, 0: "Step:" line */
+    int32_t  saved;        /* 1: "[saved]" */
+    float    loss_val, regul, obj, obj_best;
+    int32_t  rank, rank_best;
+    int32_t  dim;
+    double   auc, auc_best;
+    float    fpr95, fpr95_best;
+    double   vtime;        /* seconds spent in this call (Vtime) */
+} dlco_log_entry;
+/* Runs the LogStep block once: validation, best-objective test, stats and save rule.
+ * Keeps W_Best / W_Save / A_Save inside the context. */
+int dlco_log_step(dlco_ctx *ctx, dlco_log_entry *out);
+/* W_Save [r,F] and A_Save [F,F] (src/pj-learn.cpp:592-597); *r = 0 when nothing was saved. */
+int dlco_get_saved(dlco_ctx *ctx, float *W_host, int32_t *r, float *A_host);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* When enabled, every launch of the gradient SYRK kernel is bracketed by HIP events on the
+ * context's stream; dlco_profile_read returns launches and their summed duration. */
+int dlco_profile_enable(dlco_ctx *ctx, int32_t on);
+int dlco_profile_read(dlco_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
+/* Tracker statistics since creation: filter/RR iterations, H-products (in rows), restarts. */
+int dlco_eig_stats(const dlco_ctx *ctx, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps,
+                   int32_t *block_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

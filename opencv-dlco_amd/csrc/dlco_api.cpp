@@ -1,0 +1,828 @@
+// dlco_api.cpp — C ABI of libdlco.so (see include/dlco.h).  Host orchestration of the
+// pj-learn step on one MI355X; every arithmetic stage runs in a HIP kernel of this library.
+#include "../../include/dlco.h"
+
+#include "dlco_internal.hpp"
+#include "eig_tracker.hpp"
+#include "pair_index.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+using namespace dlco;
+
+static thread_local std::string g_last_error;
+
+struct dlco_ctx {
+    dlco_cfg cfg{};
+    int F = 0, N = 0, B = 0, Bl = 0, lo = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop{};
+
+    // data
+    DevBuf<float> dists_own;
+    const float *dists = nullptr;
+    std::vector<uint8_t> labels;
+    DevBuf<uint8_t> labels_dev;
+    PairIndex idx;
+    DevBuf<int32_t> val_pos_ids, val_neg_ids;
+    bool have_data = false;
+
+    // training state
+    CvRng rng{2215};
+    uint32_t t = 0;
+    int r = 0;                       // rows of W (0 = the reference's all-zero F x F W)
+    double traceA = 0.0;
+    DevBuf<float> dfavg, grad, W;
+    int w_cap = 0;
+    std::vector<int32_t> h_pos_rows, h_neg_rows;
+    DevBuf<int32_t> pos_rows, neg_rows, local_ids, rho, kappa, act_ids, seed_ids;
+    DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
+    DevBuf<int> k_active;
+    DevBuf<double> dscal;
+    size_t proj_slab_floats = 0;
+    int phase = 0;                   // 0 idle, 1 after begin, 2 after grad
+    EigTracker *eig = nullptr;
+    RocWork *roc = nullptr;
+    int64_t nonconv_steps = 0;
+
+    // model selection (src/pj-learn.cpp:229-232)
+    double auc_best = 0.0;
+    float obj_best = FLT_MAX, fpr95_best = FLT_MAX;
+    int r_best = 0;
+    std::vector<float> W_save, A_save;
+    int r_save = 0;
+
+    // profiling of the gradient SYRK
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_n = 0;
+};
+
+namespace {
+
+constexpr int VCHUNK = 16384;
+
+template <typename Fn>
+int guarded(const dlco_ctx *ctx, Fn &&fn)
+{
+    try {
+        fn();
+        return DLCO_OK;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        if (ctx) const_cast<dlco_ctx *>(ctx)->err = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        if (ctx) const_cast<dlco_ctx *>(ctx)->err = e.what();
+        return DLCO_ERR_INVALID;
+    }
+}
+
+void sync(dlco_ctx *c) { DLCO_HIP(hipStreamSynchronize(c->stream)); }
+
+void h2d(dlco_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    DLCO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    sync(c);
+}
+void d2h(dlco_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    DLCO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+}
+
+void finish_data(dlco_ctx *c, const uint8_t *labels_host)
+{
+    c->labels.assign(labels_host, labels_host + c->N);
+    c->labels_dev.alloc(c->N);
+    h2d(c, c->labels_dev.p, c->labels.data(), c->N);
+    c->idx.build(c->labels.data(), c->N);
+    const int npv = (int)c->idx.pos.size() - c->idx.n_pos_trn, nnv = (int)c->idx.neg.size() - c->idx.n_neg_trn;
+    c->val_pos_ids.alloc(std::max(npv, 1));
+    c->val_neg_ids.alloc(std::max(nnv, 1));
+    if (npv > 0) h2d(c, c->val_pos_ids.p, c->idx.pos.data() + c->idx.n_pos_trn, (size_t)npv * sizeof(int32_t));
+    if (nnv > 0) h2d(c, c->val_neg_ids.p, c->idx.neg.data() + c->idx.n_neg_trn, (size_t)nnv * sizeof(int32_t));
+    c->vdist.alloc((size_t)c->N + 16);
+    c->hrows.alloc((size_t)std::max(npv, 1));
+    if (c->roc) roc_work_destroy(c->roc);
+    c->roc = roc_work_create(c->N);
+    c->have_data = true;
+}
+
+// dist[i] = |W x_{row(i)}|^2 for many rows (validation / statistics): chunked GEMM, fused square-sum
+void project_many(dlco_ctx *c, const int32_t *ids_dev, int row0, int n, const float *Wd, int r, float *out_dev)
+{
+    if (n <= 0) return;
+    if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
+    c->vproj.alloc((size_t)r * VCHUNK);
+    for (int c0 = 0; c0 < n; c0 += VCHUNK) {
+        const int nc = std::min(VCHUNK, n - c0);
+        GemmArgs g;
+        g.M = r; g.N = nc; g.K = c->F;
+        g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
+        g.B.ld = c->F; g.B.kmajor = false;
+        if (ids_dev) { g.B.p = c->dists; g.B.row_ids = ids_dev + c0; }
+        else g.B.p = c->dists + (size_t)(row0 + c0) * c->F;
+        g.C = c->vproj.p; g.ldc = VCHUNK;
+        gemm_f32(g, c->stream);
+        sqdist_from_proj(c->vproj.p, 1, r, nc, VCHUNK, out_dev + c0, c->stream);
+    }
+}
+
+// few rows (the training batch): split-K slabs summed in order, then squared
+void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, int r, float *out_dev)
+{
+    if (n <= 0) return;
+    if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
+    const int bm = r <= 64 ? 64 : 128, bn = n <= 64 ? 64 : 128;
+    const long tiles = (long)((r + bm - 1) / bm) * ((n + bn - 1) / bn);
+    long split = std::max(1L, std::min((1024 + tiles - 1) / tiles, (long)c->F / 64));
+    const size_t need = (size_t)split * r * n;
+    if (need > c->proj_slab_floats) { c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+    GemmArgs g;
+    g.M = r; g.N = n; g.K = c->F;
+    g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
+    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = false; g.B.row_ids = ids_dev;
+    g.split_k = (int)split; g.slab = c->proj_slab.p; g.raw_slab = true;
+    int used = 1;
+    g.split_out = &used;
+    gemm_f32(g, c->stream);
+    sqdist_from_proj(c->proj_slab.p, used, r, n, n, out_dev, c->stream);
+}
+
+hipEvent_t next_event(dlco_ctx *c)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        DLCO_HIP(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+void drain_events(dlco_ctx *c)
+{
+    if (c->ev_used == 0) return;
+    sync(c);
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.f;
+        DLCO_HIP(hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
+        c->prof_ms += ms;
+        c->prof_n++;
+    }
+    c->ev_used = 0;
+}
+
+// dst = beta*dst_in + alpha * X^T diag(w) X over the active rows (upper triangle computed, mirrored)
+void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev, int kmax, float alpha, float beta,
+               float *dst)
+{
+    GemmArgs g;
+    g.M = c->F; g.N = c->F; g.K = kmax;
+    g.A.p = c->dists; g.A.ld = c->F; g.A.kmajor = true; g.A.row_ids = ids; g.A.row_scale = w;
+    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = true; g.B.row_ids = ids;
+    g.C = dst; g.ldc = c->F;
+    g.alpha = alpha; g.beta = beta;
+    g.k_dev = k_dev;
+    g.upper_only = true;
+    if (c->prof) {
+        if (c->ev_used + 2 > 4096) drain_events(c);
+        hipEvent_t e0 = next_event(c), e1 = next_event(c);
+        DLCO_HIP(hipEventRecord(e0, c->stream));
+        gemm_f32(g, c->stream);
+        DLCO_HIP(hipEventRecord(e1, c->stream));
+    } else {
+        gemm_f32(g, c->stream);
+    }
+}
+
+void rda_coeffs(const dlco_ctx *c, float *alpha, float *beta)
+{
+    // src/pj-learn.cpp:422: addWeighted(dfAvg, (double)t/(t+1), dLoss, 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg)
+    const unsigned t = c->t, B = (unsigned)c->B;
+    *beta = (float)((double)t / (t + 1));
+    *alpha = 1.0f / (float)(unsigned)(B * B * (t + 1));
+}
+
+void step_begin(dlco_ctx *c)
+{
+    DLCO_CHECK(c->have_data, DLCO_ERR_INVALID, "dlco_step: no data set");
+    DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_step_begin: previous step not finished");
+    DLCO_CHECK(c->idx.n_pos_trn > 0 && c->idx.n_neg_trn > 0, DLCO_ERR_INVALID, "dlco_step: empty training split");
+    const int B = c->B, Bl = c->Bl;
+    // R3 (src/pj-learn.cpp:310-314): interleaved draws, the same list on every rank
+    for (int k = 0; k < B; k++) {
+        const int ip = c->rng.uniform(0, c->idx.n_pos_trn);
+        const int in = c->rng.uniform(0, c->idx.n_neg_trn);
+        c->h_pos_rows[k] = c->idx.pos[ip];
+        c->h_neg_rows[k] = c->idx.neg[in];
+    }
+    DLCO_HIP(hipMemcpyAsync(c->pos_rows.p, c->h_pos_rows.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->neg_rows.p, c->h_neg_rows.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->local_ids.p, c->h_pos_rows.data() + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->local_ids.p + Bl, c->h_neg_rows.data() + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    sync(c);   // host vectors are reused next step
+    // P1+P2 on this rank's slots -> its slice of the exchange buffer
+    project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->dist_x.p + (size_t)c->cfg.rank * 2 * Bl);
+    c->phase = 1;
+}
+
+void step_grad(dlco_ctx *c)
+{
+    DLCO_CHECK(c->phase == 1, DLCO_ERR_INVALID, "dlco_step_grad: call dlco_step_begin first");
+    const int B = c->B, Bl = c->Bl, world = c->cfg.world;
+    for (int g = 0; g < world; g++) {
+        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->dist_x.p + (size_t)g * 2 * Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->dist_x.p + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+    viol_counts(c->pd.p, c->nd.p, B, c->rho.p, c->kappa.p, c->stream);
+    build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, c->lo, c->lo + Bl, c->act_ids.p,
+                      c->act_w.p, c->k_active.p, c->stream);
+    float alpha, beta;
+    rda_coeffs(c, &alpha, &beta);
+    if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p);
+    else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->grad.p);
+    c->phase = 2;
+}
+
+void step_finish(dlco_ctx *c)
+{
+    DLCO_CHECK(c->phase == 2, DLCO_ERR_INVALID, "dlco_step_finish: call dlco_step_grad first");
+    if (c->cfg.world > 1) {
+        float alpha, beta;
+        rda_coeffs(c, &alpha, &beta);
+        axpby_inplace(c->dfavg.p, c->grad.p, beta, alpha, (size_t)c->F * c->F, c->stream);
+    }
+    // E1/E2.  Cold tracker: the range of dfAvg after the first step is spanned by the batch rows,
+    // so they seed the block (global batch: every rank holds the full row lists and counts).
+    if (c->eig->block_rows() == 0) {
+        build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, c->B, 0, c->B, c->seed_ids.p, c->seed_w.p,
+                          c->k_active.p + 1, c->stream);
+        int k = 0;
+        d2h(c, &k, c->k_active.p + 1, sizeof(int));
+        if (k > 0) c->eig->seed_rows(c->dists, c->F, c->seed_ids.p, k);
+    }
+    const float cscale = (float)(std::sqrt((double)c->t + 1.0) / (double)c->cfg.gamma);
+    bool conv = true;
+    c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
+    if (!conv) c->nonconv_steps++;
+    c->t++;
+    c->phase = 0;
+}
+
+void get_W_host(dlco_ctx *c, float *W_host, int32_t *r)
+{
+    if (c->r > 0) {
+        if (W_host) d2h(c, W_host, c->W.p, (size_t)c->r * c->F * sizeof(float));
+        if (r) *r = c->r;
+    } else {
+        if (W_host) std::memset(W_host, 0, (size_t)c->F * c->F * sizeof(float));   // src/pj-learn.cpp:489-490
+        if (r) *r = c->F;
+    }
+}
+
+// A = W^T W into the scratch `grad` buffer (device)
+void build_A(dlco_ctx *c, const float *Wd, int r)
+{
+    if (r <= 0) { fill_f32(c->grad.p, 0.f, (size_t)c->F * c->F, c->stream); return; }
+    GemmArgs g;
+    g.M = c->F; g.N = c->F; g.K = r;
+    g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = true;
+    g.B.p = Wd; g.B.ld = c->F; g.B.kmajor = true;
+    g.C = c->grad.p; g.ldc = c->F;
+    g.upper_only = true;
+    gemm_f32(g, c->stream);
+}
+
+void validate(dlco_ctx *c, float *loss_val, float *regul, int32_t *rank)
+{
+    DLCO_CHECK(c->have_data, DLCO_ERR_INVALID, "dlco_validate: no data set");
+    const int npv = (int)c->idx.pos.size() - c->idx.n_pos_trn, nnv = (int)c->idx.neg.size() - c->idx.n_neg_trn;
+    DLCO_CHECK(npv > 0 && nnv > 0, DLCO_ERR_INVALID, "dlco_validate: empty validation split");
+    float *pdv = c->vdist.p, *ndv = c->vdist.p + npv;
+    project_many(c, c->val_pos_ids.p, 0, npv, c->W.p, c->r, pdv);
+    project_many(c, c->val_neg_ids.p, 0, nnv, c->W.p, c->r, ndv);
+    hinge_rows(pdv, npv, ndv, nnv, c->hrows.p, c->stream);
+    sum_f32_to_f64(c->hrows.p, npv, c->dscal.p, c->stream);
+    double total = 0.0;
+    d2h(c, &total, c->dscal.p, sizeof(double));
+    const float Loss = (float)total;                               // src/pj-learn.cpp:520
+    *loss_val = Loss / (float)npv / (float)nnv;                    // :524
+    *regul = (float)((double)c->cfg.mu * c->traceA);               // :527, trace(A) = sum of kept eigenvalues
+    if (rank) *rank = c->r > 0 ? c->r : c->F;
+}
+
+void stats(dlco_ctx *c, const float *Wd, int r, int32_t *dim, float *fpr95, double *auc)
+{
+    DLCO_CHECK(c->have_data, DLCO_ERR_INVALID, "dlco_stats: no data set");
+    project_many(c, nullptr, 0, c->N, Wd, r, c->vdist.p);
+    roc_stats(c->roc, c->vdist.p, c->labels_dev.p, c->N, fpr95, auc, c->stream);
+    if (dim) *dim = r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+void dlco_cfg_default(dlco_cfg *cfg)
+{
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->B = 200; cfg->mu = 0.001f; cfg->gamma = 0.5f; cfg->seed = 2215;
+    cfg->device = 0; cfg->rank = 0; cfg->world = 1;
+    cfg->eig_tol = 2e-4f; cfg->eig_guard = 32; cfg->eig_max_iter = 40;
+}
+
+const char *dlco_version(void) { return "dlco-mi355x 0.1 (gfx950)"; }
+
+const char *dlco_last_error(const dlco_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
+{
+    if (!out || !cfg) { g_last_error = "dlco_ctx_create: null argument"; return DLCO_ERR_INVALID; }
+    *out = nullptr;
+    dlco_ctx *c = nullptr;
+    int rc = guarded(nullptr, [&] {
+        DLCO_CHECK(cfg->F >= 4 && cfg->F % 4 == 0, DLCO_ERR_INVALID, "F must be a positive multiple of 4");
+        DLCO_CHECK(cfg->N >= 2 && cfg->B >= 1, DLCO_ERR_INVALID, "N >= 2 and B >= 1 required");
+        DLCO_CHECK(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, DLCO_ERR_INVALID, "bad rank/world");
+        DLCO_CHECK(cfg->B % cfg->world == 0, DLCO_ERR_INVALID, "B must be divisible by world");
+        DLCO_CHECK(cfg->gamma > 0.f, DLCO_ERR_INVALID, "gamma must be positive");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev)
+            throw Error(DLCO_ERR_NODEVICE, "no usable HIP device (this library has no CPU fallback)");
+        DLCO_HIP(hipSetDevice(cfg->device));
+        c = new dlco_ctx();
+        c->cfg = *cfg;
+        if (c->cfg.eig_tol <= 0.f) c->cfg.eig_tol = 2e-4f;
+        if (c->cfg.eig_guard <= 0) c->cfg.eig_guard = 32;
+        if (c->cfg.eig_max_iter <= 0) c->cfg.eig_max_iter = 40;
+        DLCO_HIP(hipGetDeviceProperties(&c->prop, cfg->device));
+        if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0)
+            throw Error(DLCO_ERR_NODEVICE, std::string("device is ") + c->prop.gcnArchName + ", this build targets gfx950 only");
+        c->F = cfg->F; c->N = cfg->N; c->B = cfg->B;
+        c->Bl = cfg->B / cfg->world; c->lo = cfg->rank * c->Bl;
+        c->rng = CvRng(cfg->seed);
+        DLCO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        const size_t FF = (size_t)c->F * c->F;
+        c->dfavg.alloc(FF); c->dfavg.zero(c->stream);
+        c->grad.alloc(FF);
+        const int max_rows = std::max(1024, 2 * c->B + c->cfg.eig_guard);
+        c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
+        c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
+        c->W.alloc((size_t)c->w_cap * c->F);
+        const int B = c->B;
+        c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
+        c->pos_rows.alloc(B); c->neg_rows.alloc(B); c->local_ids.alloc(2 * c->Bl);
+        c->rho.alloc(B); c->kappa.alloc(B);
+        c->act_ids.alloc(2 * B); c->act_w.alloc(2 * B); c->seed_ids.alloc(2 * B); c->seed_w.alloc(2 * B);
+        c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
+        c->k_active.alloc(4);
+        c->dscal.alloc(4);
+        sync(c);
+    });
+    if (rc != DLCO_OK) { delete c; return rc; }
+    *out = c;
+    return DLCO_OK;
+}
+
+void dlco_ctx_destroy(dlco_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->eig;
+    if (c->roc) roc_work_destroy(c->roc);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dlco_device_name(const dlco_ctx *c, char *buf, size_t cap, int *cc_major, int *cc_minor)
+{
+    if (!c || !buf || cap == 0) return DLCO_ERR_INVALID;
+    std::snprintf(buf, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cc_major) *cc_major = c->prop.major;
+    if (cc_minor) *cc_minor = c->prop.minor;
+    return DLCO_OK;
+}
+
+int dlco_set_data(dlco_ctx *c, const float *dists_host, const uint8_t *labels_host)
+{
+    if (!c || !dists_host || !labels_host) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        c->dists_own.alloc((size_t)c->N * c->F);
+        h2d(c, c->dists_own.p, dists_host, (size_t)c->N * c->F * sizeof(float));
+        c->dists = c->dists_own.p;
+        finish_data(c, labels_host);
+    });
+}
+
+int dlco_set_data_device(dlco_ctx *c, const float *dists_dev, const uint8_t *labels_host)
+{
+    if (!c || !dists_dev || !labels_host) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        c->dists = dists_dev;
+        finish_data(c, labels_host);
+    });
+}
+
+int dlco_synth_data(dlco_ctx *c, const float *U_host, int32_t k, uint64_t seed, float sigma_pos, float sigma_neg,
+                    float noise)
+{
+    if (!c || !U_host || k < 1 || k > 4096) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        c->dists_own.alloc((size_t)c->N * c->F);
+        DevBuf<float> U;
+        U.alloc((size_t)k * c->F);
+        h2d(c, U.p, U_host, (size_t)k * c->F * sizeof(float));
+        synth_rows(c->dists_own.p, c->N, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, c->stream);
+        sync(c);
+        c->dists = c->dists_own.p;
+        std::vector<uint8_t> lab(c->N);
+        for (int i = 0; i < c->N; i++) lab[i] = (i % 2 == 0) ? 1 : 0;
+        finish_data(c, lab.data());
+    });
+}
+
+int dlco_get_rows(dlco_ctx *c, int32_t row0, int32_t n, float *out_host)
+{
+    if (!c || !out_host) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->have_data && row0 >= 0 && n >= 0 && row0 + n <= c->N, DLCO_ERR_INVALID, "dlco_get_rows: range");
+        d2h(c, out_host, c->dists + (size_t)row0 * c->F, (size_t)n * c->F * sizeof(float));
+    });
+}
+
+int dlco_get_index(const dlco_ctx *c, int32_t *pos, int32_t *n_pos, int32_t *n_pos_trn, int32_t *neg, int32_t *n_neg,
+                   int32_t *n_neg_trn)
+{
+    if (!c || !c->have_data) return DLCO_ERR_INVALID;
+    if (pos) std::memcpy(pos, c->idx.pos.data(), c->idx.pos.size() * sizeof(int32_t));
+    if (neg) std::memcpy(neg, c->idx.neg.data(), c->idx.neg.size() * sizeof(int32_t));
+    if (n_pos) *n_pos = (int32_t)c->idx.pos.size();
+    if (n_neg) *n_neg = (int32_t)c->idx.neg.size();
+    if (n_pos_trn) *n_pos_trn = c->idx.n_pos_trn;
+    if (n_neg_trn) *n_neg_trn = c->idx.n_neg_trn;
+    return DLCO_OK;
+}
+
+int dlco_step_begin(dlco_ctx *c) { return c ? guarded(c, [&] { DLCO_HIP(hipSetDevice(c->cfg.device)); step_begin(c); }) : DLCO_ERR_INVALID; }
+int dlco_step_grad(dlco_ctx *c) { return c ? guarded(c, [&] { DLCO_HIP(hipSetDevice(c->cfg.device)); step_grad(c); }) : DLCO_ERR_INVALID; }
+int dlco_step_finish(dlco_ctx *c) { return c ? guarded(c, [&] { DLCO_HIP(hipSetDevice(c->cfg.device)); step_finish(c); }) : DLCO_ERR_INVALID; }
+
+int dlco_step(dlco_ctx *c)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->cfg.world == 1, DLCO_ERR_INVALID, "dlco_step: world > 1 needs the begin/grad/finish protocol");
+        step_begin(c); step_grad(c); step_finish(c);
+    });
+}
+
+int dlco_steps(dlco_ctx *c, int32_t n)
+{
+    for (int i = 0; i < n; i++) {
+        const int rc = dlco_step(c);
+        if (rc != DLCO_OK) return rc;
+    }
+    return DLCO_OK;
+}
+
+int dlco_dev_buffer(dlco_ctx *c, int32_t which, void **dev_ptr, size_t *bytes)
+{
+    if (!c || !dev_ptr || !bytes) return DLCO_ERR_INVALID;
+    const size_t FF = (size_t)c->F * c->F * sizeof(float);
+    switch (which) {
+    case DLCO_BUF_DIST: *dev_ptr = c->dist_x.p; *bytes = (size_t)2 * c->B * sizeof(float); return DLCO_OK;
+    case DLCO_BUF_GRAD: *dev_ptr = c->grad.p; *bytes = FF; return DLCO_OK;
+    case DLCO_BUF_DFAVG: *dev_ptr = c->dfavg.p; *bytes = FF; return DLCO_OK;
+    case DLCO_BUF_W: *dev_ptr = c->W.p; *bytes = (size_t)c->r * c->F * sizeof(float); return DLCO_OK;
+    default: return DLCO_ERR_INVALID;
+    }
+}
+
+int dlco_stream(dlco_ctx *c, void **stream)
+{
+    if (!c || !stream) return DLCO_ERR_INVALID;
+    *stream = (void *)c->stream;
+    return DLCO_OK;
+}
+
+int dlco_sync(dlco_ctx *c) { return c ? guarded(c, [&] { sync(c); }) : DLCO_ERR_INVALID; }
+
+int dlco_get_batch(const dlco_ctx *cc, int32_t *pos_rows, int32_t *neg_rows, float *pos_dist, float *neg_dist,
+                   int32_t *rho, int32_t *kappa)
+{
+    dlco_ctx *c = const_cast<dlco_ctx *>(cc);
+    if (!c) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        const size_t B = c->B;
+        if (pos_rows) std::memcpy(pos_rows, c->h_pos_rows.data(), B * sizeof(int32_t));
+        if (neg_rows) std::memcpy(neg_rows, c->h_neg_rows.data(), B * sizeof(int32_t));
+        if (pos_dist) d2h(c, pos_dist, c->pd.p, B * sizeof(float));
+        if (neg_dist) d2h(c, neg_dist, c->nd.p, B * sizeof(float));
+        if (rho) d2h(c, rho, c->rho.p, B * sizeof(int32_t));
+        if (kappa) d2h(c, kappa, c->kappa.p, B * sizeof(int32_t));
+    });
+}
+
+int dlco_get_t(const dlco_ctx *c, uint32_t *t)
+{
+    if (!c || !t) return DLCO_ERR_INVALID;
+    *t = c->t;
+    return DLCO_OK;
+}
+
+int dlco_get_W(dlco_ctx *c, float *W_host, int32_t *r) { return c ? guarded(c, [&] { get_W_host(c, W_host, r); }) : DLCO_ERR_INVALID; }
+
+int dlco_get_A(dlco_ctx *c, float *A_host)
+{
+    if (!c || !A_host) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_A: step in flight");
+        build_A(c, c->W.p, c->r);
+        d2h(c, A_host, c->grad.p, (size_t)c->F * c->F * sizeof(float));
+    });
+}
+
+int dlco_get_dfavg(dlco_ctx *c, float *out)
+{
+    if (!c || !out) return DLCO_ERR_INVALID;
+    return guarded(c, [&] { d2h(c, out, c->dfavg.p, (size_t)c->F * c->F * sizeof(float)); });
+}
+
+int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float *W_host, int32_t r)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_set_state: step in flight");
+        DLCO_CHECK(r >= 0 && r <= c->w_cap, DLCO_ERR_INVALID, "dlco_set_state: r out of range");
+        c->t = t;
+        if (dfavg_host) h2d(c, c->dfavg.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+        c->eig->reset();
+        if (W_host && r > 0) {
+            h2d(c, c->W.p, W_host, (size_t)r * c->F * sizeof(float));
+            c->r = r;
+            c->eig->seed_rows(c->W.p, c->F, nullptr, r);
+        } else {
+            c->r = 0;
+        }
+    });
+}
+
+int dlco_validate(dlco_ctx *c, float *loss_val, float *regul, int32_t *rank)
+{
+    if (!c || !loss_val || !regul) return DLCO_ERR_INVALID;
+    return guarded(c, [&] { DLCO_HIP(hipSetDevice(c->cfg.device)); validate(c, loss_val, regul, rank); });
+}
+
+int dlco_stats(dlco_ctx *c, const float *W_host, int32_t r, int32_t *dim, float *fpr95, double *auc)
+{
+    if (!c || !fpr95 || !auc) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        if (!W_host) { stats(c, c->W.p, c->r, dim, fpr95, auc); return; }
+        // S1 (src/misc.cpp:269-277): keep the rows of W that have a non-zero entry
+        std::vector<float> nz;
+        int rows = 0;
+        for (int i = 0; i < r; i++) {
+            const float *row = W_host + (size_t)i * c->F;
+            bool any = false;
+            for (int f = 0; f < c->F && !any; f++) any = row[f] != 0.0f;
+            if (any) { nz.insert(nz.end(), row, row + c->F); rows++; }
+        }
+        DevBuf<float> Wd;
+        Wd.alloc((size_t)std::max(rows, 1) * c->F);
+        if (rows) h2d(c, Wd.p, nz.data(), nz.size() * sizeof(float));
+        stats(c, Wd.p, rows, dim, fpr95, auc);
+    });
+}
+
+int dlco_project_sqdist(dlco_ctx *c, const int32_t *row_ids_host, int32_t n, const float *W_host, int32_t r,
+                        float *out_host)
+{
+    if (!c || !row_ids_host || !out_host || n < 0 || r < 0) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->have_data, DLCO_ERR_INVALID, "dlco_project_sqdist: no data set");
+        if (n == 0) return;
+        for (int i = 0; i < n; i++)
+            DLCO_CHECK(row_ids_host[i] >= 0 && row_ids_host[i] < c->N, DLCO_ERR_INVALID, "dlco_project_sqdist: row id out of range");
+        DevBuf<int32_t> ids; ids.alloc(n);
+        DevBuf<float> Wd, out; Wd.alloc((size_t)std::max(r, 1) * c->F); out.alloc(n);
+        h2d(c, ids.p, row_ids_host, (size_t)n * sizeof(int32_t));
+        if (r) h2d(c, Wd.p, W_host, (size_t)r * c->F * sizeof(float));
+        if (n <= 4096) project_few(c, ids.p, n, Wd.p, r, out.p);
+        else project_many(c, ids.p, 0, n, Wd.p, r, out.p);
+        d2h(c, out_host, out.p, (size_t)n * sizeof(float));
+    });
+}
+
+int dlco_viol_counts(dlco_ctx *c, const float *pd_host, const float *nd_host, int32_t B, int32_t *rho_host,
+                     int32_t *kappa_host)
+{
+    if (!c || !pd_host || !nd_host || !rho_host || !kappa_host || B < 0) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        if (B == 0) return;
+        DevBuf<float> pd, nd; DevBuf<int32_t> rho, kap;
+        pd.alloc(B); nd.alloc(B); rho.alloc(B); kap.alloc(B);
+        h2d(c, pd.p, pd_host, (size_t)B * sizeof(float));
+        h2d(c, nd.p, nd_host, (size_t)B * sizeof(float));
+        viol_counts(pd.p, nd.p, B, rho.p, kap.p, c->stream);
+        d2h(c, rho_host, rho.p, (size_t)B * sizeof(int32_t));
+        d2h(c, kappa_host, kap.p, (size_t)B * sizeof(int32_t));
+    });
+}
+
+int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_rows_host, const int32_t *rho_host,
+                  const int32_t *kappa_host, int32_t B, float alpha, float beta, const float *dfavg_in_host,
+                  float *dfavg_out_host)
+{
+    if (!c || !pos_rows_host || !neg_rows_host || !rho_host || !kappa_host || !dfavg_out_host || B < 1) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->have_data && c->phase == 0, DLCO_ERR_INVALID, "dlco_grad_rda: no data / step in flight");
+        for (int i = 0; i < B; i++)
+            DLCO_CHECK(pos_rows_host[i] >= 0 && pos_rows_host[i] < c->N && neg_rows_host[i] >= 0 && neg_rows_host[i] < c->N,
+                       DLCO_ERR_INVALID, "dlco_grad_rda: row id out of range");
+        DevBuf<int32_t> pr, nr, rho, kap, ids; DevBuf<float> w; DevBuf<int> k;
+        pr.alloc(B); nr.alloc(B); rho.alloc(B); kap.alloc(B); ids.alloc(2 * B); w.alloc(2 * B); k.alloc(1);
+        h2d(c, pr.p, pos_rows_host, (size_t)B * sizeof(int32_t));
+        h2d(c, nr.p, neg_rows_host, (size_t)B * sizeof(int32_t));
+        h2d(c, rho.p, rho_host, (size_t)B * sizeof(int32_t));
+        h2d(c, kap.p, kappa_host, (size_t)B * sizeof(int32_t));
+        const size_t FF = (size_t)c->F * c->F;
+        if (dfavg_in_host) h2d(c, c->grad.p, dfavg_in_host, FF * sizeof(float));
+        else fill_f32(c->grad.p, 0.f, FF, c->stream);
+        build_active_rows(pr.p, nr.p, rho.p, kap.p, B, 0, B, ids.p, w.p, k.p, c->stream);
+        grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, c->grad.p);
+        d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));
+    });
+}
+
+int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_host, int32_t *r, float *A_host)
+{
+    if (!c || !dfavg_host || !r) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_psd_project: step in flight");
+        const size_t FF = (size_t)c->F * c->F;
+        DevBuf<float> G;
+        G.alloc(FF);
+        h2d(c, G.p, dfavg_host, FF * sizeof(float));
+        c->eig->reset();
+        const float cscale = (float)(std::sqrt((double)t + 1.0) / (double)c->cfg.gamma);
+        double tr = 0.0;
+        bool conv = true;
+        DevBuf<float> Wd;
+        Wd.alloc((size_t)c->w_cap * c->F);
+        const int rr = c->eig->update(G.p, c->cfg.mu, cscale, Wd.p, &tr, &conv);
+        c->eig->reset();
+        if (rr > 0) {
+            if (W_host) d2h(c, W_host, Wd.p, (size_t)rr * c->F * sizeof(float));
+            *r = rr;
+        } else {
+            if (W_host) std::memset(W_host, 0, FF * sizeof(float));
+            *r = c->F;
+        }
+        if (A_host) {
+            build_A(c, Wd.p, rr);
+            d2h(c, A_host, c->grad.p, FF * sizeof(float));
+        }
+        if (!conv) throw Error(DLCO_ERR_NOCONV, "dlco_psd_project: tracker did not reach its tolerance");
+    });
+}
+
+int dlco_hinge_sum(dlco_ctx *c, const float *pos_host, int32_t n_pos, const float *neg_host, int32_t n_neg, double *out)
+{
+    if (!c || !out || n_pos < 0 || n_neg < 0) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        *out = 0.0;
+        if (n_pos == 0) return;
+        DevBuf<float> p, n, rows;
+        p.alloc(n_pos); n.alloc(std::max(n_neg, 1)); rows.alloc(n_pos);
+        h2d(c, p.p, pos_host, (size_t)n_pos * sizeof(float));
+        if (n_neg) h2d(c, n.p, neg_host, (size_t)n_neg * sizeof(float));
+        hinge_rows(p.p, n_pos, n.p, n_neg, rows.p, c->stream);
+        sum_f32_to_f64(rows.p, n_pos, c->dscal.p, c->stream);
+        d2h(c, out, c->dscal.p, sizeof(double));
+    });
+}
+
+int dlco_roc_stats(dlco_ctx *c, const float *dist_host, const uint8_t *labels_host, int32_t n, float *fpr95, double *auc)
+{
+    if (!c || !dist_host || !labels_host || !fpr95 || !auc || n < 1) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DevBuf<float> d; DevBuf<uint8_t> l;
+        d.alloc(n); l.alloc(n);
+        h2d(c, d.p, dist_host, (size_t)n * sizeof(float));
+        h2d(c, l.p, labels_host, (size_t)n);
+        RocWork *w = roc_work_create(n);
+        try { roc_stats(w, d.p, l.p, n, fpr95, auc, c->stream); } catch (...) { roc_work_destroy(w); throw; }
+        roc_work_destroy(w);
+    });
+}
+
+int dlco_log_step(dlco_ctx *c, dlco_log_entry *out)
+{
+    if (!c || !out) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_log_step: step in flight");
+        const auto t0 = std::chrono::steady_clock::now();
+        std::memset(out, 0, sizeof(*out));
+        // the reference prints the loop variable t of the iteration that just ran (src/pj-learn.cpp:538)
+        out->t = c->t - 1;
+        float loss = 0.f, regul = 0.f;
+        int32_t rank = 0;
+        validate(c, &loss, &regul, &rank);
+        const auto t1 = std::chrono::steady_clock::now();
+        out->loss_val = loss; out->regul = regul; out->obj = loss + regul; out->rank = rank;
+        if ((loss + regul) < c->obj_best) {                        // :532
+            c->obj_best = loss + regul;
+            c->r_best = rank;
+            out->is_best = 1;
+            int32_t dim = 0; float f95 = 0.f; double auc = 0.0;
+            stats(c, c->W.p, c->r, &dim, &f95, &auc);                // :551
+            out->dim = dim; out->auc = auc; out->fpr95 = f95;
+            if (c->auc_best <= auc && c->fpr95_best >= f95) {       // :558-559
+                c->auc_best = auc; c->fpr95_best = f95;
+                c->W_save.resize((size_t)std::max(rank, 1) * c->F);
+                int32_t rr = 0;
+                get_W_host(c, c->W_save.data(), &rr);
+                c->W_save.resize((size_t)rr * c->F);
+                c->r_save = rr;
+                c->A_save.resize((size_t)c->F * c->F);
+                build_A(c, c->W.p, c->r);
+                d2h(c, c->A_save.data(), c->grad.p, c->A_save.size() * sizeof(float));
+                out->saved = 1;
+            }
+        }
+        out->obj_best = c->obj_best; out->rank_best = c->r_best;
+        out->auc_best = c->auc_best; out->fpr95_best = c->fpr95_best;
+        out->vtime = std::chrono::duration<double>(t1 - t0).count();
+    });
+}
+
+int dlco_get_saved(dlco_ctx *c, float *W_host, int32_t *r, float *A_host)
+{
+    if (!c || !r) return DLCO_ERR_INVALID;
+    *r = c->r_save;
+    if (c->r_save > 0) {
+        if (W_host) std::memcpy(W_host, c->W_save.data(), c->W_save.size() * sizeof(float));
+        if (A_host) std::memcpy(A_host, c->A_save.data(), c->A_save.size() * sizeof(float));
+    }
+    return DLCO_OK;
+}
+
+int dlco_profile_enable(dlco_ctx *c, int32_t on)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        drain_events(c);
+        c->prof = on != 0;
+        if (on) { c->prof_ms = 0.0; c->prof_n = 0; }
+    });
+}
+
+int dlco_profile_read(dlco_ctx *c, const char *kernel, int64_t *launches, double *total_ms)
+{
+    if (!c || !launches || !total_ms) return DLCO_ERR_INVALID;
+    (void)kernel;
+    return guarded(c, [&] {
+        drain_events(c);
+        *launches = c->prof_n;
+        *total_ms = c->prof_ms;
+    });
+}
+
+int dlco_eig_stats(const dlco_ctx *c, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps, int32_t *block_rows)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    const EigStats &s = c->eig->stats();
+    if (iters) *iters = s.iters;
+    if (product_rows) *product_rows = s.product_rows;
+    if (jacobi_sweeps) *jacobi_sweeps = s.jacobi_sweeps;
+    if (block_rows) *block_rows = c->eig->block_rows();
+    return DLCO_OK;
+}
+
+}  // extern "C"

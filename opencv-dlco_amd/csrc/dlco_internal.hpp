@@ -1,0 +1,152 @@
+// dlco_internal.hpp — shared declarations for libdlco.so (gfx950 only).
+// Host side C++17, device side HIP.  No torch types, no OpenCV, no CUDA shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dlco {
+
+// ---------------------------------------------------------------------------
+// error handling: exceptions inside the library, converted to codes at the ABI
+// ---------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define DLCO_HIP(expr)                                                             \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess)                                                     \
+            throw ::dlco::Error(-3, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define DLCO_CHECK(cond, code, msg)                                                \
+    do {                                                                           \
+        if (!(cond)) throw ::dlco::Error((code), std::string(msg));                \
+    } while (0)
+
+// simple owning device buffer
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        if (count <= n && p) return;
+        release();
+        if (count == 0) count = 1;
+        DLCO_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void zero(hipStream_t s) { if (p) DLCO_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// ---------------------------------------------------------------------------
+// generic fp32 MFMA GEMM (kernels_gemm.hip)
+//   C[M,N] = alpha * A(M,K) * B(K,N)  (+ epilogue)
+// Operand addressing:
+//   A.kmajor : element (i,k) at A.p[row(k)*A.ld + i]   (memory rows run along K)
+//   else     : element (i,k) at A.p[row(i)*A.ld + k]   (memory rows run along M)
+//   B.kmajor : element (k,j) at B.p[row(k)*B.ld + j]
+//   else     : element (k,j) at B.p[row(j)*B.ld + k]
+//   row(x) = row_ids ? row_ids[x] : x ; k-major rows may carry a per-row scale.
+// Epilogue:  C = alpha*acc + beta*C_in + b1*E1 + b2*E2   (E1/E2 share C's ld)
+// ---------------------------------------------------------------------------
+struct GemmOperand {
+    const float *p = nullptr;
+    long ld = 0;
+    bool kmajor = false;
+    const int32_t *row_ids = nullptr;
+    const float *row_scale = nullptr;   // only for k-major operands
+};
+
+struct GemmArgs {
+    int M = 0, N = 0, K = 0;
+    GemmOperand A, B;
+    float *C = nullptr;
+    long ldc = 0;
+    float alpha = 1.0f, beta = 0.0f;
+    const float *E1 = nullptr;
+    float b1 = 0.0f;
+    const float *E2 = nullptr;
+    float b2 = 0.0f;
+    const int *k_dev = nullptr;         // optional device-resident K (<= K)
+    int split_k = 1;                    // >1: partial slabs + ordered reduce
+    float *slab = nullptr;              // workspace >= split_k*M*N floats when split_k > 1
+    bool upper_only = false;            // M==N: compute tiles with j-block >= i-block, mirror the rest
+    bool raw_slab = false;              // keep the [split][M][N] partials in `slab`, skip the reduce (C unused)
+    int *split_out = nullptr;           // receives the number of K slices actually used
+};
+
+void gemm_f32(const GemmArgs &a, hipStream_t s);
+size_t gemm_slab_floats(int M, int N, int split_k);
+
+// ---------------------------------------------------------------------------
+// step kernels (kernels_step.hip)
+// ---------------------------------------------------------------------------
+// dist[j] = sum_q (sum_z slab[z][q][j])^2 for a [split][r][n] projection slab
+void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s);
+// rho/kappa + signed weights + compact active list for one batch
+//   pd, nd: [B] distances; out rho[B], kappa[B]; weights[2B] (rho_i for positives, -kappa_j for negatives)
+void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, hipStream_t s);
+// build the stacked weighted row list of the SYRK: ids[2B] = (pos rows, neg rows), w[2B] = (rho, -kappa);
+// rows with zero weight are dropped; *k_active receives the count. [lo,hi) selects the slots owned by a rank.
+void build_active_rows(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho, const int32_t *kappa,
+                       int B, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s);
+// per-row sequential hinge sum (src/kernelop-opencv.cu:49-66), rows then summed in double
+void hinge_rows(const float *pos, int n_pos, const float *neg, int n_neg, float *row_sums, hipStream_t s);
+void sum_f32_to_f64(const float *x, int n, double *out, hipStream_t s);
+void trace_f64(const float *A, int F, long ld, double *out, hipStream_t s);
+void axpby_inplace(float *y, const float *x, float a, float b, size_t n, hipStream_t s);  // y = a*y + b*x
+void scale_rows(float *dst, long ldd, const float *src, long lds, const float *scale, const int32_t *src_rows,
+                int rows, int cols, hipStream_t s);                                        // dst[i] = scale[i]*src[src_rows[i]]
+void fill_f32(float *p, float v, size_t n, hipStream_t s);
+
+// synthetic stand-in for a *-unproj.h5 generated in HBM (bench): d = U^T z + eps, clipped
+void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
+                float noise, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// small dense eigen problems on one workgroup (kernels_eig.hip)
+// ---------------------------------------------------------------------------
+// One-sided Jacobi on a symmetric n x n matrix T (ld = ldt).  Output: evals[n] descending,
+// V[n][ldv] with COLUMN j = eigenvector j.  work: >= 2*n*n + 4*n floats.  n <= 1024.
+void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
+                 hipStream_t s);
+size_t jacobi_work_floats(int n);
+// row norms of (Y - theta_i X) and of X
+void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
+                    hipStream_t s);
+void row_normalize(float *X, long ld, int m, int F, hipStream_t s);
+// y = H x style GEMV on a symmetric matrix (memory-bound), used by the spectral-bound estimator
+void symv(const float *H, long ld, int F, const float *x, float *y, hipStream_t s);
+// whitening coefficient matrix Cw[n][k] = U[:, keep] * lam^-1/2 for eigenvalues above thresh*lam_max; returns k on host
+void build_whitener(const float *evals, const float *V, long ldv, int n, float rel_thresh, float *Cw, long ldcw,
+                    int *k_out_dev, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// ROC statistics on device (kernels_stats.hip) — src/misc.cpp:297-332
+// ---------------------------------------------------------------------------
+struct RocWork;
+RocWork *roc_work_create(int n_max);
+void roc_work_destroy(RocWork *w);
+void roc_stats(RocWork *w, const float *dist_dev, const uint8_t *labels_dev, int n, float *fpr95, double *auc,
+               hipStream_t s);
+
+}  // namespace dlco

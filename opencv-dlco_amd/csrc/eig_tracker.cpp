@@ -1,0 +1,317 @@
+// eig_tracker.cpp — host orchestration of the positive-eigenspace tracker (see the header).
+#include "eig_tracker.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <initializer_list>
+
+namespace dlco {
+
+namespace {
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+}  // namespace
+
+EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream)
+    : F_(F), guard_(guard), max_iter_(max_iter), tol_(tol), s_(stream)
+{
+    cap_ = std::min(F, std::max(max_rows, 2 * guard + 32));
+    if (guard_ > cap_ / 2) guard_ = std::max(1, cap_ / 2);
+    for (int i = 0; i < 6; i++) { buf_[i].alloc((size_t)cap_ * F_); all_[i] = buf_[i].p; }
+    Q_ = all_[0]; Y_ = all_[1];
+    Tm_.alloc((size_t)cap_ * cap_);
+    Vm_.alloc((size_t)cap_ * cap_);
+    Cw_.alloc((size_t)cap_ * cap_);
+    evals_.alloc(cap_ + 8);
+    res_.alloc(cap_ + 8);
+    scale_.alloc(cap_ + 8);
+    srcrow_.alloc(cap_ + 8);
+    jwork_.alloc(jacobi_work_floats(cap_));
+    ibuf_.alloc(8);
+    pv_.alloc(F_);
+    pw_.alloc(F_);
+    slab_floats_ = std::max((size_t)4 * cap_ * F_, (size_t)8 << 20);
+    slab_floats_ = std::min(slab_floats_, (size_t)64 << 20);
+    slab_floats_ = std::max(slab_floats_, (size_t)cap_ * F_);
+    slab_.alloc(slab_floats_);
+    pin_floats_ = (size_t)3 * cap_ + 64;
+    DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float)));
+    h_theta_.assign(cap_, 0.f);
+    h_res_.assign(cap_, 0.f);
+}
+
+EigTracker::~EigTracker()
+{
+    if (pin_) (void)hipHostFree(pin_);
+}
+
+float *EigTracker::pick(std::initializer_list<const float *> busy) const
+{
+    for (int i = 0; i < 6; i++) {
+        bool used = false;
+        for (const float *b : busy) used = used || (b == all_[i]);
+        if (!used) return all_[i];
+    }
+    throw Error(-2, "eig tracker: no free work buffer");
+}
+
+void EigTracker::reset()
+{
+    m_ = 0;
+    have_theta_ = false;
+    have_lo_ = false;
+    steps_since_lo_ = 0;
+}
+
+void EigTracker::seed_rows(const float *src, long ld, const int32_t *ids_dev, int n)
+{
+    const int k = std::min(n, cap_);
+    have_theta_ = false;
+    if (k <= 0) { m_ = 0; return; }
+    scale_rows(Q_, F_, src, ld, nullptr, ids_dev, k, F_, s_);
+    m_ = k;
+}
+
+float EigTracker::next_uniform()
+{
+    rng_ ^= rng_ << 13; rng_ ^= rng_ >> 7; rng_ ^= rng_ << 17;
+    return (float)((double)(rng_ >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+}
+
+void EigTracker::append_random(float *Q, int have, int add)
+{
+    if (add <= 0) return;
+    h_tmp_.resize((size_t)add * F_);
+    for (size_t i = 0; i < h_tmp_.size(); i++) h_tmp_[i] = next_uniform();
+    DLCO_HIP(hipMemcpyAsync(Q + (size_t)have * F_, h_tmp_.data(), h_tmp_.size() * sizeof(float), hipMemcpyHostToDevice, s_));
+    DLCO_HIP(hipStreamSynchronize(s_));
+}
+
+// out[rows][F] = alpha * X*G + b1*E1 + b2*E2     (G symmetric F x F)
+void EigTracker::product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
+                         const float *E2, float b2)
+{
+    GemmArgs g;
+    g.M = rows; g.N = F_; g.K = F_;
+    g.A.p = X; g.A.ld = F_; g.A.kmajor = false;
+    g.B.p = G; g.B.ld = F_; g.B.kmajor = true;
+    g.C = out; g.ldc = F_;
+    g.alpha = alpha; g.E1 = E1; g.b1 = b1; g.E2 = E2; g.b2 = b2;
+    const int bm = rows <= 64 ? 64 : 128;
+    const long tiles = (long)ceil_div(rows, bm) * ceil_div(F_, 128);
+    long split = std::max(1L, std::min((long)ceil_div(1024, tiles), (long)F_ / 256));
+    split = std::min(split, (long)(slab_floats_ / ((size_t)rows * F_)));
+    g.split_k = (int)std::max(1L, split);
+    g.slab = slab_.p;
+    gemm_f32(g, s_);
+    st_.product_rows += rows;
+}
+
+// T[rows][rows] (ld cap_) = X * Y^T
+void EigTracker::gram(const float *X, const float *Y, int rows, float *T)
+{
+    GemmArgs g;
+    g.M = rows; g.N = rows; g.K = F_;
+    g.A.p = X; g.A.ld = F_; g.A.kmajor = false;
+    g.B.p = Y; g.B.ld = F_; g.B.kmajor = false;
+    g.C = T; g.ldc = cap_;
+    const int bt = rows <= 64 ? 64 : 128;
+    const long tiles = (long)ceil_div(rows, bt) * ceil_div(rows, bt);
+    long split = std::max(1L, std::min((long)ceil_div(512, tiles), (long)F_ / 64));
+    split = std::min(split, (long)(slab_floats_ / ((size_t)rows * rows)));
+    g.split_k = (int)std::max(1L, split);
+    g.slab = slab_.p;
+    gemm_f32(g, s_);
+}
+
+// out[k_out][F] = C^T X with C [k_in][ldc] holding the coefficient vectors in its columns
+void EigTracker::rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out)
+{
+    GemmArgs g;
+    g.M = k_out; g.N = F_; g.K = k_in;
+    g.A.p = C; g.A.ld = ldc; g.A.kmajor = true;
+    g.B.p = X; g.B.ld = F_; g.B.kmajor = true;
+    g.C = out; g.ldc = F_;
+    gemm_f32(g, s_);
+}
+
+// One whitening pass dst = Lambda^-1/2 U^T src from the eigendecomposition of the Gram
+// matrix; rank-revealing (directions below 1e-6 of the largest Gram eigenvalue are dropped).
+int EigTracker::whiten(const float *src, int k, float *dst, bool *well_conditioned)
+{
+    gram(src, src, k, Tm_.p);
+    jacobi_eigh(Tm_.p, cap_, k, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
+    build_whitener(evals_.p, Vm_.p, cap_, k, 1e-6f, Cw_.p, cap_, ibuf_.p, s_);
+    int *hi = reinterpret_cast<int *>(pin_);
+    DLCO_HIP(hipMemcpyAsync(hi, ibuf_.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s_));
+    DLCO_HIP(hipMemcpyAsync(pin_ + 8, evals_.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s_));
+    DLCO_HIP(hipStreamSynchronize(s_));
+    const int kept = hi[0];
+    st_.jacobi_sweeps += hi[1];
+    DLCO_CHECK(kept >= 1, -5, "eig tracker: basis collapsed during orthonormalisation");
+    if (well_conditioned) *well_conditioned = pin_[8 + kept - 1] > 0.25f * pin_[8];
+    rotate(Cw_.p, cap_, k, kept, src, dst);
+    return kept;
+}
+
+// Orthonormalise the rows of Z (clobbered) into `out`; returns the kept row count.
+int EigTracker::orthonormalize(float *Z, int rows, float *out)
+{
+    row_normalize(Z, F_, rows, F_, s_);
+    bool ok = false;
+    const int k1 = whiten(Z, rows, out, &ok);
+    if (ok) return k1;
+    const int k2 = whiten(out, k1, Z, nullptr);
+    DLCO_HIP(hipMemcpyAsync(out, Z, (size_t)k2 * F_ * sizeof(float), hipMemcpyDeviceToDevice, s_));
+    return k2;
+}
+
+// Power iteration for lambda_max(G); the lower end of H = -G is -lambda_max(G).
+void EigTracker::refresh_lower_bound(const float *G, int iters, float theta_top)
+{
+    static const float kZero = 0.f;
+    const bool cold = !have_lo_;
+    if (cold) {
+        std::vector<float> v(F_);
+        for (int i = 0; i < F_; i++) v[i] = next_uniform();
+        DLCO_HIP(hipMemcpyAsync(pv_.p, v.data(), F_ * sizeof(float), hipMemcpyHostToDevice, s_));
+        DLCO_HIP(hipStreamSynchronize(s_));
+        row_normalize(pv_.p, F_, 1, F_, s_);
+    }
+    DLCO_HIP(hipMemcpyAsync(scale_.p, &kZero, sizeof(float), hipMemcpyHostToDevice, s_));   // theta = 0: plain norm
+    auto run = [&](float shift, int n) -> float {
+        float *v = pv_.p, *w = pw_.p;
+        for (int i = 0; i < n; i++) {
+            symv(G, F_, F_, v, w, s_);
+            if (shift != 0.f) axpby_inplace(w, v, 1.0f, shift, F_, s_);
+            if (i == n - 1) residual_norms(v, w, F_, scale_.p, 1, F_, res_.p, s_);   // |w|
+            row_normalize(w, F_, 1, F_, s_);
+            std::swap(v, w);
+        }
+        if (v != pv_.p) DLCO_HIP(hipMemcpyAsync(pv_.p, v, F_ * sizeof(float), hipMemcpyDeviceToDevice, s_));
+        DLCO_HIP(hipMemcpyAsync(pin_, res_.p, sizeof(float), hipMemcpyDeviceToHost, s_));
+        DLCO_HIP(hipStreamSynchronize(s_));
+        return pin_[0];
+    };
+    // |G v| <= spectral radius; the shift must dominate -lambda_min(G) = top eigenvalue of H
+    const float rho = run(0.f, cold ? 12 : 2);
+    const float shift = std::max(cold ? 2.0f * rho : 1.05f * rho, 1.1f * std::max(theta_top, 0.f)) + 1e-30f;
+    const float top = run(shift, iters) - shift;        // <= lambda_max(G), tight once converged
+    const float lam_max = std::max(top, 0.f);
+    lo_bound_ = -(1.3f * lam_max + 0.05f * std::max(rho, theta_top)) - 1e-12f;
+    have_lo_ = true;
+    steps_since_lo_ = 0;
+}
+
+int EigTracker::update(const float *G, float mu, float cscale, float *W, double *trace, bool *converged)
+{
+    st_.updates++;
+    if (m_ == 0) {
+        m_ = std::min(cap_, 2 * guard_ + 32);
+        append_random(Q_, 0, m_);
+        have_theta_ = false;
+    }
+    float theta_top = have_theta_ ? h_theta_[0] : 0.f;
+    float block_min = have_theta_ ? std::min(h_theta_[m_ - 1], mu) : mu;
+    steps_since_lo_++;
+    const int period = st_.updates < 20 ? 1 : (st_.updates < 200 ? 5 : 20);
+    if (!have_lo_) refresh_lower_bound(G, 30, theta_top);
+    else if (steps_since_lo_ >= period) refresh_lower_bound(G, 6, theta_top);
+
+    bool conv = false;
+    int nw = 0, it = 0;
+    for (; it < max_iter_; it++) {
+        float *Z = Q_;
+        if (m_ < F_) {
+            // ---- Chebyshev filter of degree d damping [a, b] of H = -G ---------------------------
+            const float a = lo_bound_;
+            float b = std::min(block_min, mu);
+            const float minw = 1e-3f * (std::fabs(a) + std::fabs(mu)) + 1e-20f;
+            if (b < a + minw) b = a + minw;
+            const float c0 = 0.5f * (a + b), e0 = 0.5f * (b - a);
+            int d = it == 0 ? 4 : (it == 1 ? 6 : (it < 4 ? 8 : 10));
+            const float xmax = std::max(1.5f, (std::max(theta_top, mu) - c0) / e0);
+            const int dcap = (int)(28.0f / std::log10(2.0f * xmax));       // keep T_d(xmax) inside fp32
+            d = std::max(2, std::min(d, dcap));
+            const float *prev = Q_;
+            float *cur = pick({Q_});
+            product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f);
+            for (int k = 2; k <= d; k++) {
+                float *nxt = pick({prev, cur});
+                product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f);
+                prev = cur; cur = nxt;
+            }
+            Z = cur;
+        }
+        // ---- orthonormalise, Rayleigh-Ritz -------------------------------------------------------
+        float *Qo = pick({Z});
+        m_ = orthonormalize(Z, m_, Qo);
+        float *Yb = pick({Qo});
+        product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f);            // Yb = Qo * H
+        gram(Yb, Qo, m_, Tm_.p);
+        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
+        float *Qn = pick({Qo, Yb});
+        rotate(Vm_.p, cap_, m_, m_, Qo, Qn);
+        float *Yn = pick({Qo, Yb, Qn});
+        rotate(Vm_.p, cap_, m_, m_, Yb, Yn);
+        Q_ = Qn; Y_ = Yn;
+        residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
+        DLCO_HIP(hipMemcpyAsync(pin_, evals_.p, (size_t)m_ * sizeof(float), hipMemcpyDeviceToHost, s_));
+        DLCO_HIP(hipMemcpyAsync(pin_ + cap_, res_.p, (size_t)m_ * sizeof(float), hipMemcpyDeviceToHost, s_));
+        DLCO_HIP(hipMemcpyAsync(pin_ + 2 * cap_, ibuf_.p + 1, sizeof(int), hipMemcpyDeviceToHost, s_));
+        DLCO_HIP(hipStreamSynchronize(s_));
+        std::memcpy(h_theta_.data(), pin_, (size_t)m_ * sizeof(float));
+        std::memcpy(h_res_.data(), pin_ + cap_, (size_t)m_ * sizeof(float));
+        st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * cap_);
+        have_theta_ = true;
+        theta_top = h_theta_[0];
+        block_min = std::min(h_theta_[m_ - 1], mu);
+
+        nw = 0;
+        while (nw < m_ && h_theta_[nw] > mu) nw++;
+        float crit = 0.f;
+        for (int i = 0; i < nw; i++) crit = std::max(crit, cscale * h_res_[i]);
+        const float emax = nw > 0 ? cscale * (h_theta_[0] - mu) : 0.f;
+        last_crit_ = emax > 0.f ? crit / emax : 0.f;
+        if (m_ >= F_) conv = true;                                   // dense: Rayleigh-Ritz is exact
+        else if (nw == 0) conv = (h_theta_[0] + h_res_[0] < mu) || it >= 2;
+        else conv = crit <= tol_ * emax;
+        if (h_theta_[m_ - 1] < lo_bound_) lo_bound_ = h_theta_[m_ - 1] - 0.5f * std::fabs(h_theta_[m_ - 1]) - 1e-12f;
+        // ---- grow the block when the positive eigenspace reaches into the guard ------------------
+        if (m_ < F_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {
+            const int add = std::min(cap_ - m_, std::max(guard_, nw / 4));
+            append_random(Q_, m_, add);
+            for (int i = m_; i < m_ + add; i++) { h_theta_[i] = block_min; h_res_[i] = 0.f; }
+            m_ += add;
+            conv = false;
+            continue;
+        }
+        if (conv) { it++; break; }
+    }
+    st_.iters += it;
+    if (!conv) st_.nonconverged++;
+    if (converged) *converged = conv;
+
+    // ---- trim the block, emit W (ascending eigenvalue order, like LAPACK's) ----------------------
+    m_ = std::max(1, std::min(m_, nw + guard_));
+    double tr = 0.0;
+    if (nw > 0) {
+        h_sc_.resize(nw);
+        h_sr_.resize(nw);
+        for (int j = 0; j < nw; j++) {
+            const int i = nw - 1 - j;
+            const float e = cscale * (h_theta_[i] - mu);
+            h_sc_[j] = std::sqrt(e);
+            h_sr_[j] = i;
+            tr += (double)e;
+        }
+        DLCO_HIP(hipMemcpyAsync(scale_.p, h_sc_.data(), nw * sizeof(float), hipMemcpyHostToDevice, s_));
+        DLCO_HIP(hipMemcpyAsync(srcrow_.p, h_sr_.data(), nw * sizeof(int32_t), hipMemcpyHostToDevice, s_));
+        DLCO_HIP(hipStreamSynchronize(s_));
+        scale_rows(W, F_, Q_, F_, scale_.p, srcrow_.p, nw, F_, s_);
+    }
+    if (trace) *trace = tr;
+    return nw;
+}
+
+}  // namespace dlco

@@ -1,0 +1,80 @@
+// eig_tracker.hpp — positive-eigenspace tracker for the PSD projection of the pj-learn
+// step (E1/E2, src/pj-learn.cpp:434-490).
+//
+// The reference eigendecomposes the full F x F matrix A = -(sqrt(t+1)/gamma)(dfAvg + mu I)
+// with LAPACKE_ssyevr every step and keeps only the eigenpairs with a positive eigenvalue.
+// Here only those pairs are computed: with H = -dfAvg they are the eigenpairs of H above
+// mu.  A block of m = r + guard Ritz vectors is carried from step to step and refreshed by
+// Chebyshev-filtered subspace iteration (filter damps [lambda_min(H), lowest Ritz value of
+// the block]) followed by one Rayleigh-Ritz step; all tall products are fp32 MFMA GEMMs,
+// the m x m problems run on one workgroup (one-sided Jacobi).  The block grows when the
+// positive eigenspace does; when it reaches F the method is the dense eigensolver.
+#pragma once
+
+#include "dlco_internal.hpp"
+
+#include <initializer_list>
+
+namespace dlco {
+
+struct EigStats {
+    int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0;
+};
+
+class EigTracker {
+public:
+    EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream);
+    ~EigTracker();
+
+    // Forget the subspace (next update seeds from `seed_rows` or random vectors).
+    void reset();
+    // Seed the block with `n` rows gathered from a device matrix (ids may be NULL = rows 0..n-1).
+    void seed_rows(const float *src, long ld, const int32_t *ids_dev, int n);
+
+    // Track the eigenpairs of H = -G above mu.  cscale = sqrt(t+1)/gamma.
+    // Writes W [r][F] (rows sqrt(cscale*(theta-mu)) * q, ascending like LAPACK) and returns r.
+    // *trace receives sum of cscale*(theta-mu) (trace of the projected A).
+    int update(const float *G, float mu, float cscale, float *W, double *trace, bool *converged);
+
+    int block_rows() const { return m_; }
+    const EigStats &stats() const { return st_; }
+    float last_crit() const { return last_crit_; }
+
+private:
+    void product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
+                 const float *E2, float b2);
+    void gram(const float *X, const float *Y, int rows, float *T);
+    void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out);
+    int whiten(const float *src, int k, float *dst, bool *well_conditioned);
+    int orthonormalize(float *Z, int rows, float *out);          // returns kept rows
+    void refresh_lower_bound(const float *G, int iters, float theta_top);
+    void append_random(float *Q, int have, int add);
+    float next_uniform();
+    float *pick(std::initializer_list<const float *> busy) const;
+
+    int F_, cap_, guard_, max_iter_;
+    float tol_;
+    hipStream_t s_;
+    int m_ = 0;                      // rows currently in the block
+    bool have_theta_ = false;
+    float lo_bound_ = 0.f;           // lower bound of H's spectrum
+    bool have_lo_ = false;
+    int steps_since_lo_ = 0;
+    uint64_t rng_ = 0x243F6A8885A308D3ULL;
+    float last_crit_ = 0.f;
+
+    DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F
+    float *all_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *Q_ = nullptr, *Y_ = nullptr;
+    DevBuf<float> Tm_, Vm_, Cw_, evals_, res_, jwork_, slab_, pv_, pw_, scale_;
+    DevBuf<int32_t> srcrow_;
+    DevBuf<int> ibuf_;               // [0] kept count, [1] sweeps
+    size_t slab_floats_ = 0;
+    std::vector<float> h_theta_, h_res_, h_tmp_, h_sc_;
+    std::vector<int32_t> h_sr_;
+    float *pin_ = nullptr;           // pinned host staging
+    size_t pin_floats_ = 0;
+    EigStats st_;
+};
+
+}  // namespace dlco

@@ -1,0 +1,284 @@
+// kernels_gemm.hip — generic fp32 GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// One templated kernel serves every GEMM-shaped piece of the pj-learn path that is
+// not the fused SYRK (kernels_syrk.hip): projection W*X^T, subspace products Q*H,
+// Gram / Rayleigh matrices, basis rotations.  64-wide wavefronts, four waves per
+// workgroup in a 2x2 arrangement, each wave owning WM x WN tiles of 32x32, LDS tiles
+// stored k-major so that both MFMA operand fragments are conflict-free ds_read_b32
+// (lane l reads element (l&31) of row k = 2*kk + (l>>5)).  Exact fp32: the MFMA is a
+// k-ordered fmaf chain (MI355X guide, "FP32-input MFMA").
+#include "dlco_internal.hpp"
+
+namespace dlco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+constexpr int NT = 256;
+
+struct OperandDev {
+    const float *p;
+    long ld;
+    const int32_t *row_ids;
+    const float *row_scale;
+    int vec_ok;
+};
+
+struct GemmDev {
+    int M, N, K;
+    OperandDev A, B;
+    float *C;
+    long ldc;
+    float alpha, beta, b1, b2;
+    const float *E1, *E2;
+    const int *k_dev;
+    int k_chunk;      // K range per blockIdx.z
+    float *slab;      // != nullptr: write raw partials to slab[z][M][N]
+    int upper_only;
+};
+
+// Stage one BK x BT tile of an operand into LDS (k-major image [BK][BT+PAD]).
+// KM = memory rows run along K (contiguous along the M/N index), else along M/N.
+template <int BT, bool KM>
+__device__ __forceinline__ void load_tile(const OperandDev &op, int t0, int tmax, int k0, int kend,
+                                          f32x4 (&regs)[BT / 64])
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < BT / 64; u++) {
+        const int f = tid + NT * u;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KM) {
+            const int row = f / (BT / 4), c4 = f % (BT / 4);
+            const int k = k0 + row, col = t0 + c4 * 4;
+            if (k < kend && col < tmax) {
+                const long mr = op.row_ids ? (long)op.row_ids[k] : (long)k;
+                const float *src = op.p + mr * op.ld + col;
+                if (op.vec_ok && col + 3 < tmax) {
+                    v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+                    v[0] = src[0];
+                    if (col + 1 < tmax) v[1] = src[1];
+                    if (col + 2 < tmax) v[2] = src[2];
+                    if (col + 3 < tmax) v[3] = src[3];
+                }
+                if (op.row_scale) {
+                    const float sc = op.row_scale[k];
+                    v *= sc;
+                }
+            }
+        } else {
+            const int row = f / (BK / 4), kq = f % (BK / 4);
+            const int t = t0 + row, k = k0 + kq * 4;
+            if (t < tmax && k < kend) {
+                const long mr = op.row_ids ? (long)op.row_ids[t] : (long)t;
+                const float *src = op.p + mr * op.ld + k;
+                if (op.vec_ok && k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+                    v[0] = src[0];
+                    if (k + 1 < kend) v[1] = src[1];
+                    if (k + 2 < kend) v[2] = src[2];
+                    if (k + 3 < kend) v[3] = src[3];
+                }
+            }
+        }
+        regs[u] = v;
+    }
+}
+
+template <int BT, bool KM>
+__device__ __forceinline__ void store_tile(float (*lds)[BT + PAD], const f32x4 (&regs)[BT / 64])
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < BT / 64; u++) {
+        const int f = tid + NT * u;
+        if (KM) {
+            const int row = f / (BT / 4), c4 = f % (BT / 4);
+            *reinterpret_cast<f32x4 *>(&lds[row][c4 * 4]) = regs[u];
+        } else {
+            const int row = f / (BK / 4), kq = f % (BK / 4);
+            lds[kq * 4 + 0][row] = regs[u][0];
+            lds[kq * 4 + 1][row] = regs[u][1];
+            lds[kq * 4 + 2][row] = regs[u][2];
+            lds[kq * 4 + 3][row] = regs[u][3];
+        }
+    }
+}
+
+template <int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmDev g)
+{
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (g.upper_only && bj * BN + BN <= bi * BM) return;     // tile entirely below the diagonal
+    const int i0 = bi * BM, j0 = bj * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int kbeg = blockIdx.z * g.k_chunk;
+    int kend = min(g.K, kbeg + g.k_chunk);
+    if (g.k_dev) kend = min(kend, *g.k_dev);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; a++)
+#pragma unroll
+        for (int b = 0; b < WN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    f32x4 ra[BM / 64], rb[BN / 64];
+    if (nk > 0) {
+        load_tile<BM, A_KM>(g.A, i0, g.M, kbeg, kend, ra);
+        load_tile<BN, B_KM>(g.B, j0, g.N, kbeg, kend, rb);
+        store_tile<BM, A_KM>(As[0], ra);
+        store_tile<BN, B_KM>(Bs[0], rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<BM, A_KM>(g.A, i0, g.M, kbeg + (kt + 1) * BK, kend, ra);
+            load_tile<BN, B_KM>(g.B, j0, g.N, kbeg + (kt + 1) * BK, kend, rb);
+        }
+        const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            float af[WM], bf[WN];
+#pragma unroll
+            for (int a = 0; a < WM; a++) af[a] = As[buf][2 * kk + lk][wm * 32 * WM + a * 32 + lr];
+#pragma unroll
+            for (int b = 0; b < WN; b++) bf[b] = Bs[buf][2 * kk + lk][wn * 32 * WN + b * 32 + lr];
+#pragma unroll
+            for (int a = 0; a < WM; a++)
+#pragma unroll
+                for (int b = 0; b < WN; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tile<BM, A_KM>(As[buf ^ 1], ra);
+            store_tile<BN, B_KM>(Bs[buf ^ 1], rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int lc = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < WM; a++)
+#pragma unroll
+        for (int b = 0; b < WN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wm * 32 * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int j = j0 + wn * 32 * WN + b * 32 + lc;
+                if (i >= g.M || j >= g.N) continue;
+                if (g.slab) {
+                    g.slab[((long)blockIdx.z * g.M + i) * g.N + j] = acc[a][b][r];
+                    continue;
+                }
+                if (g.upper_only && j < i) continue;
+                const long idx = (long)i * g.ldc + j;
+                float o = g.alpha * acc[a][b][r];
+                if (g.beta != 0.f) o += g.beta * g.C[idx];
+                if (g.E1) o += g.b1 * g.E1[idx];
+                if (g.E2) o += g.b2 * g.E2[idx];
+                g.C[idx] = o;
+                if (g.upper_only && j > i) g.C[(long)j * g.ldc + i] = o;
+            }
+}
+
+__global__ void splitk_reduce_kernel(const float *slab, int split, int M, int N, float *C, long ldc, float alpha,
+                                     float beta, const float *E1, float b1, const float *E2, float b2)
+{
+    const long total = (long)M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        float s = 0.f;
+        for (int z = 0; z < split; z++) s += slab[(long)z * total + e];   // fixed order: deterministic
+        const long idx = (long)i * ldc + j;
+        float o = alpha * s;
+        if (beta != 0.f) o += beta * C[idx];
+        if (E1) o += b1 * E1[idx];
+        if (E2) o += b2 * E2[idx];
+        C[idx] = o;
+    }
+}
+
+template <int WM, int WN>
+void launch(const GemmDev &g, bool akm, bool bkm, dim3 grid, hipStream_t s)
+{
+    if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<WM, WN, true, true>), grid, dim3(NT), 0, s, g);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_kernel<WM, WN, true, false>), grid, dim3(NT), 0, s, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<WM, WN, false, true>), grid, dim3(NT), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, false, false>), grid, dim3(NT), 0, s, g);
+}
+
+inline int vec_ok(const GemmOperand &o) { return (o.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(o.p) & 15) == 0); }
+
+}  // namespace
+
+size_t gemm_slab_floats(int M, int N, int split_k) { return split_k > 1 ? (size_t)split_k * M * N : 0; }
+
+void gemm_f32(const GemmArgs &a, hipStream_t s)
+{
+    if (a.M <= 0 || a.N <= 0) return;
+    DLCO_CHECK(a.A.p && a.B.p && (a.C || a.raw_slab), -2, "gemm_f32: null operand");
+    DLCO_CHECK(!(a.upper_only && (a.M != a.N || a.split_k > 1)), -2, "gemm_f32: upper_only needs M==N, split_k==1");
+    GemmDev g;
+    g.M = a.M; g.N = a.N; g.K = a.K;
+    g.A = {a.A.p, a.A.ld, a.A.row_ids, a.A.kmajor ? a.A.row_scale : nullptr, vec_ok(a.A)};
+    g.B = {a.B.p, a.B.ld, a.B.row_ids, a.B.kmajor ? a.B.row_scale : nullptr, vec_ok(a.B)};
+    g.C = a.C; g.ldc = a.ldc;
+    g.alpha = a.alpha; g.beta = a.beta; g.E1 = a.E1; g.b1 = a.b1; g.E2 = a.E2; g.b2 = a.b2;
+    g.k_dev = a.k_dev;
+    g.upper_only = a.upper_only ? 1 : 0;
+    int split = a.split_k < 1 ? 1 : a.split_k;
+    int chunk = (a.K + split - 1) / split;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    if (chunk < BK) chunk = BK;
+    split = a.K > 0 ? (a.K + chunk - 1) / chunk : 1;
+    g.k_chunk = chunk;
+    g.slab = nullptr;
+    if (split > 1 || a.raw_slab) {
+        DLCO_CHECK(a.slab != nullptr, -2, "gemm_f32: split_k > 1 needs a slab workspace");
+        g.slab = a.slab;
+    }
+    if (a.split_out) *a.split_out = split;
+    // tile choice: the small dimension decides
+    const bool small_m = a.M <= 64, small_n = a.N <= 64;
+    if (small_m && small_n) {
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, split);
+        launch<1, 1>(g, a.A.kmajor, a.B.kmajor, grid, s);
+    } else if (small_m) {
+        dim3 grid((a.N + 127) / 128, (a.M + 63) / 64, split);
+        launch<1, 2>(g, a.A.kmajor, a.B.kmajor, grid, s);
+    } else if (small_n) {
+        dim3 grid((a.N + 63) / 64, (a.M + 127) / 128, split);
+        launch<2, 1>(g, a.A.kmajor, a.B.kmajor, grid, s);
+    } else {
+        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, split);
+        launch<2, 2>(g, a.A.kmajor, a.B.kmajor, grid, s);
+    }
+    DLCO_HIP(hipGetLastError());
+    if (split > 1 && !a.raw_slab) {
+        const long total = (long)a.M * a.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)a.slab, split, a.M, a.N,
+                           a.C, a.ldc, a.alpha, a.beta, a.E1, a.b1, a.E2, a.b2);
+        DLCO_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace dlco

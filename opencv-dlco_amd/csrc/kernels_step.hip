@@ -1,0 +1,259 @@
+// kernels_step.hip — the small (non-GEMM) kernels of one pj-learn step and of the
+// validation pass, for gfx950.  References are to the reference checkout
+// (cbalint13/opencv-dlco).
+#include "dlco_internal.hpp"
+
+namespace dlco {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// P2 (src/pj-learn.cpp:346-347): dist_j = sum_q proj[q][j]^2, rows added one after another in fp32
+__global__ void sqdist_kernel(const float *proj, int split, int r, int n, long ld, float *dist)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long plane = (long)r * ld;
+    float d = 0.f;
+    for (int q = 0; q < r; q++) {
+        float p = 0.f;
+        for (int z = 0; z < split; z++) p += proj[z * plane + (long)q * ld + j];
+        d += p * p;
+    }
+    dist[j] = d;
+}
+
+// V1 (src/pj-learn.cpp:373-376): strict (pd_i + 1.0f) > nd_j
+__global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa)
+{
+    extern __shared__ float sh[];
+    float *spd = sh, *snd = sh + B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { spd[i] = pd[i] + 1.0f; snd[i] = nd[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float thr = spd[i];
+        int c = 0;
+        for (int j = 0; j < B; j++) c += (thr > snd[j]) ? 1 : 0;
+        rho[i] = c;
+        const float me = snd[i];
+        int k = 0;
+        for (int j = 0; j < B; j++) k += (spd[j] > me) ? 1 : 0;
+        kappa[i] = k;
+    }
+}
+
+// stacked, weighted, compacted row list of the gradient SYRK (slots [lo,hi) of each class)
+__global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
+                                   const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int k = 0;
+    for (int i = lo; i < hi && i < B; i++)
+        if (rho[i] != 0) { ids[k] = pos_rows[i]; w[k] = (float)rho[i]; k++; }
+    for (int j = lo; j < hi && j < B; j++)
+        if (kappa[j] != 0) { ids[k] = neg_rows[j]; w[k] = -(float)kappa[j]; k++; }
+    *k_active = k;
+    for (int z = k; z < 2 * B; z++) { ids[z] = 0; w[z] = 0.f; }
+}
+
+// H1 (src/kernelop-opencv.cu:49-66): one thread per positive row, the inner sum runs over the
+// negatives in index order in fp32 exactly as the reference kernel does:
+//   rsum = src1[idx] + 1 - src2[i]; tsum += (rsum > 0) ? rsum : 0
+__global__ __launch_bounds__(256) void hinge_rows_kernel(const float *pos, int n_pos, const float *neg, int n_neg,
+                                                         float *row_sums)
+{
+    __shared__ float sn[2048];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float base = (i < n_pos) ? pos[i] + 1.0f : 0.f;
+    float tsum = 0.f;
+    for (int j0 = 0; j0 < n_neg; j0 += 2048) {
+        const int cnt = min(2048, n_neg - j0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) sn[t] = neg[j0 + t];
+        __syncthreads();
+        for (int t = 0; t < cnt; t++) {
+            const float rsum = base - sn[t];
+            tsum += (rsum > 0.f) ? rsum : 0.f;
+        }
+    }
+    if (i < n_pos) row_sums[i] = tsum;
+}
+
+__global__ __launch_bounds__(1024) void sum_f64_kernel(const float *x, int n, double *out)
+{
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w];
+        *out = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void trace_kernel(const float *A, int F, long ld, double *out)
+{
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < F; i += blockDim.x) s += (double)A[(long)i * ld + i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w];
+        *out = t;
+    }
+}
+
+__global__ void axpby_kernel(float *y, const float *x, float a, float b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a * y[i] + b * x[i];
+}
+
+__global__ void fill_kernel(float *p, float v, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void scale_rows_kernel(float *dst, long ldd, const float *src, long lds, const float *scale,
+                                  const int32_t *src_rows, int rows, int cols)
+{
+    const int i = blockIdx.x;
+    if (i >= rows) return;
+    const long sr = src_rows ? (long)src_rows[i] : (long)i;
+    const float sc = scale ? scale[i] : 1.0f;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(long)i * ldd + c] = sc * src[sr * lds + c];
+}
+
+// ---- synthetic data ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float gauss(uint64_t key)
+{
+    const uint64_t h = splitmix(key);
+    const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0,1)
+    const float u2 = (float)(uint32_t)(h & 0xFFFFFF) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+}
+
+// row i: label 1 when i is even; d = U^T z + noise*eps, z ~ N(0, sigma^2 I_k), clipped to [-1, 1]
+__global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, const float *U, int k, uint64_t seed,
+                                                    float sig_pos, float sig_neg, float noise)
+{
+    extern __shared__ float z[];
+    const int i = blockIdx.x;
+    if (i >= N) return;
+    const float sig = (i % 2 == 0) ? sig_pos : sig_neg;
+    for (int q = threadIdx.x; q < k; q += blockDim.x)
+        z[q] = sig * gauss(seed * 0x100000001B3ULL + ((uint64_t)i << 20) + (uint64_t)q + 0x5000000000000000ULL);
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        float v = 0.f;
+        for (int q = 0; q < k; q++) v += z[q] * U[(long)q * F + f];
+        v += noise * gauss(seed * 0x100000001B3ULL + ((uint64_t)i << 20) + (uint64_t)f);
+        v = fminf(1.0f, fmaxf(-1.0f, v));
+        D[(long)i * F + f] = v;
+    }
+}
+
+}  // namespace
+
+void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sqdist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, proj, split, r, n, ld, dist);
+    DLCO_HIP(hipGetLastError());
+}
+
+void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, hipStream_t s)
+{
+    if (B <= 0) return;
+    DLCO_CHECK(B <= 8192, -2, "viol_counts: batch too large for one workgroup's LDS");
+    hipLaunchKernelGGL(viol_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), s, pd, nd, B, rho, kappa);
+    DLCO_HIP(hipGetLastError());
+}
+
+void build_active_rows(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho, const int32_t *kappa,
+                       int B, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s)
+{
+    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(64), 0, s, pos_rows, neg_rows, rho, kappa, B, slot_lo, slot_hi,
+                       ids, w, k_active);
+    DLCO_HIP(hipGetLastError());
+}
+
+void hinge_rows(const float *pos, int n_pos, const float *neg, int n_neg, float *row_sums, hipStream_t s)
+{
+    if (n_pos <= 0) return;
+    hipLaunchKernelGGL(hinge_rows_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, s, pos, n_pos, neg, n_neg, row_sums);
+    DLCO_HIP(hipGetLastError());
+}
+
+void sum_f32_to_f64(const float *x, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(1024), 0, s, x, n, out);
+    DLCO_HIP(hipGetLastError());
+}
+
+void trace_f64(const float *A, int F, long ld, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(1024), 0, s, A, F, ld, out);
+    DLCO_HIP(hipGetLastError());
+}
+
+void axpby_inplace(float *y, const float *x, float a, float b, size_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, x, a, b, n);
+    DLCO_HIP(hipGetLastError());
+}
+
+void fill_f32(float *p, float v, size_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, n);
+    DLCO_HIP(hipGetLastError());
+}
+
+void scale_rows(float *dst, long ldd, const float *src, long lds, const float *scale, const int32_t *src_rows,
+                int rows, int cols, hipStream_t s)
+{
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, scale, src_rows, rows, cols);
+    DLCO_HIP(hipGetLastError());
+}
+
+void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
+                float noise, hipStream_t s)
+{
+    hipLaunchKernelGGL(synth_kernel, dim3(N), dim3(256), k * sizeof(float), s, D, N, F, U, k, seed, sig_pos, sig_neg,
+                       noise);
+    DLCO_HIP(hipGetLastError());
+}
+
+}  // namespace dlco

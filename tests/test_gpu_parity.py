@@ -1,0 +1,330 @@
+"""GPU parity tests: the HIP path (through the C ABI of libdlco.so) against the CPU oracle
+on the same seeded inputs, plus the committed golden vectors.  Integer work (pair
+indexing, violation counts, FPR95 rank position) must be bit-exact; fp32 work carries the
+tolerance written next to each assert.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from util import golden, relmax, synth
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerances (relative to the largest magnitude of the reference quantity)
+TOL_DIST = 2e-5      # per-pair squared distances: K = F fmaf chain vs OpenBLAS sgemm order
+TOL_GRAD = 5e-6      # dfAvg after one fused SYRK + dual average, vs fp64 accumulation
+TOL_A = 5e-4         # PSD-projected A: subspace tracker tolerance (eig_tol = 2e-4) + eigen sensitivity
+TOL_LOSS = 1e-5      # validation hinge loss
+
+
+@pytest.fixture(scope="module")
+def small(dlco):
+    N, F, B = 3000, 64, 40
+    D, L = synth(N, F, k=12, seed=77)
+    ctx = dlco.Context(F, N, B=B, mu=0.005, gamma=0.5)
+    ctx.set_data(D, L)
+    yield ctx, D, L
+    ctx.close()
+
+
+def test_device_is_gfx950(small):
+    name, _, _ = small[0].device_name()
+    assert "gfx950" in name
+
+
+@pytest.mark.parametrize("mode,N", [("alternate", 5000), ("ragged", 4097), ("alternate", 2), ("ragged", 333)])
+def test_pair_index_bit_exact(dlco, ref, mode, N):
+    F = 8
+    D, L = synth(N, F, k=2, seed=N, label_mode=mode)
+    ctx = dlco.Context(F, N, B=4)
+    ctx.set_data(D, L)
+    got = ctx.index()
+    pos, neg = ref.build_index(L)
+    assert np.array_equal(got["pos"], pos) and np.array_equal(got["neg"], neg)
+    assert got["n_pos_trn"] == ref.split(pos.size) and got["n_neg_trn"] == ref.split(neg.size)
+    ctx.close()
+
+
+def test_pair_index_golden_500k(dlco):
+    z = golden("oracle_rng.npz")
+    N, F = 500000, 4
+    L = (np.arange(N) % 2 == 0).astype(np.uint8)
+    ctx = dlco.Context(F, N, B=4)
+    ctx.set_data(np.zeros((N, F), np.float32), L)
+    got = ctx.index()
+    assert np.array_equal(got["pos"][:8], z["idx500k_pos_head"]) and np.array_equal(got["pos"][-8:], z["idx500k_pos_tail"])
+    assert np.array_equal(got["neg"][:8], z["idx500k_neg_head"]) and np.array_equal(got["neg"][-8:], z["idx500k_neg_tail"])
+    w = np.arange(got["pos"].size) % 977
+    assert int((got["pos"].astype(np.int64) * w).sum()) == int(z["idx500k_pos_sum"])
+    assert int((got["neg"].astype(np.int64) * w).sum()) == int(z["idx500k_neg_sum"])
+    assert got["n_pos_trn"] == 200000 and got["n_neg_trn"] == 200000
+    ctx.close()
+
+
+def test_sampler_bit_exact(dlco, ref):
+    N, F, B = 2000, 32, 25
+    D, L = synth(N, F, k=6, seed=5)
+    ctx = dlco.Context(F, N, B=B, mu=0.01)
+    ctx.set_data(D, L)
+    tr = ref.Trainer(D, L, B=B, mu=0.01, gamma=0.5, grad_order=1)
+    for _ in range(12):
+        ctx.step()
+        tr.step()
+        b = ctx.batch()
+        pr, nr = tr.batch_ids()
+        assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+    ctx.close()
+    tr.close()
+
+
+@pytest.mark.parametrize("r,n", [(1, 7), (12, 80), (37, 400), (64, 5000), (0, 16)])
+def test_project_sqdist(small, ref, r, n):
+    ctx, D, _ = small
+    rng = np.random.default_rng(r * 1000 + n)
+    W = (rng.standard_normal((r, ctx.F)) * 0.3).astype(np.float32)
+    ids = rng.integers(0, ctx.N, n).astype(np.int32)
+    got = ctx.project_sqdist(ids, W)
+    want = ref.project_sqdist_ids(W, D, ids) if r else np.zeros(n, np.float32)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= TOL_DIST * max(want.max(), 1e-30)
+
+
+def test_project_linearity_property(small):
+    ctx, D, _ = small
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((20, ctx.F)).astype(np.float32)
+    ids = rng.integers(0, ctx.N, 300).astype(np.int32)
+    d1 = ctx.project_sqdist(ids, W)
+    d2 = ctx.project_sqdist(ids, 2.0 * W)       # scaling by 2 is exact in binary floating point
+    assert np.array_equal(d2, 4.0 * d1)
+    assert (d1 >= 0).all()
+
+
+@pytest.mark.parametrize("B", [1, 8, 200, 777])
+def test_viol_counts_exact(small, ref, B):
+    ctx = small[0]
+    rng = np.random.default_rng(B)
+    pd = rng.random(B).astype(np.float32) * 3
+    nd = rng.random(B).astype(np.float32) * 4
+    if B >= 8:   # exact ties on the strict threshold pd + 1 > nd
+        nd[:4] = pd[:4] + np.float32(1.0)
+        nd[4] = np.nextafter(pd[4] + np.float32(1.0), np.float32(-10))
+    rho, kap = ctx.viol_counts(pd, nd)
+    r2, k2 = ref.viol_counts(pd, nd)
+    assert np.array_equal(rho, r2) and np.array_equal(kap, k2)
+    assert rho.sum() == kap.sum()
+
+
+@pytest.mark.parametrize("B,zero_frac", [(40, 0.0), (40, 0.6), (17, 1.0)])
+def test_grad_rda(small, ref, B, zero_frac):
+    ctx, D, _ = small
+    rng = np.random.default_rng(B + int(zero_frac * 10))
+    pr = rng.integers(0, ctx.N, B).astype(np.int32)
+    nr = rng.integers(0, ctx.N, B).astype(np.int32)
+    rho = rng.integers(0, B + 1, B).astype(np.int32)
+    kap = rng.integers(0, B + 1, B).astype(np.int32)
+    rho[rng.random(B) < zero_frac] = 0
+    kap[rng.random(B) < zero_frac] = 0
+    df0 = rng.standard_normal((ctx.F, ctx.F)).astype(np.float32)
+    df0 = (df0 + df0.T) * np.float32(0.5)
+    alpha, beta = np.float32(1.0 / (B * B * 7)), np.float32(6.0 / 7.0)
+    got = ctx.grad_rda(pr, nr, rho, kap, float(alpha), float(beta), df0)
+    g64 = ref.grad_reform(D[pr], D[nr], rho, kap, f64=True)
+    want = np.float64(beta) * df0 + np.float64(alpha) * g64
+    assert relmax(got, want) <= TOL_GRAD
+    assert np.array_equal(got, got.T)            # upper triangle mirrored: exactly symmetric
+
+
+def test_hinge_sum(small, ref):
+    ctx = small[0]
+    rng = np.random.default_rng(11)
+    for npos, nneg in ((1, 1), (257, 3000), (5000, 5000), (64, 0)):
+        p = (rng.random(npos) * 2).astype(np.float32)
+        n = (rng.random(nneg) * 3).astype(np.float32)
+        got = ctx.hinge_sum(p, n)
+        want = ref.hinge_sum(p, n)
+        # per-row fp32 sums follow the reference kernel's order exactly; rows are added in double
+        assert abs(got - want) <= 1e-12 * max(abs(want), 1.0)
+
+
+def test_roc_stats(small, ref):
+    ctx = small[0]
+    rng = np.random.default_rng(13)
+    for n in (2, 999, 50000):
+        lab = (rng.random(n) < 0.5).astype(np.uint8)
+        lab[0], lab[1] = 1, 0
+        d = (rng.random(n) + 0.8 * (lab == 0)).astype(np.float32)
+        d[rng.integers(0, n, n // 10)] = np.float32(0.5)      # ties
+        if n > 100:
+            lab[rng.integers(0, n, 5)] = 3                        # labels that count for neither class
+        f, a = ctx.roc_stats(d, lab)
+        f2, a2 = ref.roc_stats(d, lab)
+        assert f == f2
+        assert abs(a - a2) <= 1e-12
+
+
+def _psd_case(ref, F, seed, t, mu, gamma, rank_hint):
+    rng = np.random.default_rng(seed)
+    Q = np.linalg.qr(rng.standard_normal((F, F)))[0]
+    ev = np.concatenate([-rng.random(rank_hint) * 0.5 - 0.02, rng.random(F - rank_hint) * 0.2 - 0.001])
+    G = ((Q * ev) @ Q.T).astype(np.float32)
+    G = (G + G.T) * np.float32(0.5)
+    A = ref.dual_to_primal(G, mu, gamma, t)
+    Ap, W, _ = ref.psd_project(A)
+    return G, Ap, W
+
+
+@pytest.mark.parametrize("F,rank_hint", [(64, 9), (256, 40)])
+def test_psd_project(dlco, ref, F, rank_hint):
+    mu, gamma, t = 0.004, 0.5, 17
+    G, Ap, Wref = _psd_case(ref, F, F + rank_hint, t, mu, gamma, rank_hint)
+    ctx = dlco.Context(F, 16, B=4, mu=mu, gamma=gamma)
+    W, A = ctx.psd_project(G, t)
+    assert abs(W.shape[0] - Wref.shape[0]) <= 1          # eigenvalues within fp32 noise of mu may flip
+    assert relmax(A, Ap) <= TOL_A
+    # rows ascending in eigenvalue (LAPACK order), mutually orthogonal
+    n2 = (W.astype(np.float64) ** 2).sum(1)
+    assert (np.diff(n2) >= -1e-6 * n2.max()).all()
+    Gm = W.astype(np.float64) @ W.T.astype(np.float64)
+    assert np.abs(Gm - np.diag(np.diag(Gm))).max() <= 1e-4 * n2.max()
+    ctx.close()
+
+
+@pytest.mark.parametrize("fname", ["oracle_step_F32_B8.npz", "oracle_step_F64_B40.npz"])
+def test_teacher_forced_steps_golden(dlco, ref, fname):
+    """Each recorded oracle step is replayed from the oracle's own state."""
+    z = golden(fname)
+    N, F, B, mu, gamma, nstep = z["cfg"]
+    N, F, B, nstep = int(N), int(F), int(B), int(nstep)
+    ctx = dlco.Context(F, N, B=B, mu=float(mu), gamma=float(gamma))
+    ctx.set_data(z["D"], z["L"])
+    for s in range(nstep):
+        W_in = z["s%d_W_in" % s]
+        if s == 0:
+            W_in = W_in[:0]                      # the reference starts from W = zeros(F,F): distances are 0
+        ctx.set_state(s, z["s%d_dfavg_in" % s], W_in)
+        ctx.step()
+        b = ctx.batch()
+        # the sampler state is sequential: identical because every earlier step was also run here
+        assert np.array_equal(b["pos_rows"], z["s%d_pos_rows" % s]) and np.array_equal(b["neg_rows"], z["s%d_neg_rows" % s])
+        pd, nd = z["s%d_pd" % s], z["s%d_nd" % s]
+        scale = max(pd.max(), nd.max(), 1e-30)
+        assert np.abs(b["pd"] - pd).max() <= TOL_DIST * scale and np.abs(b["nd"] - nd).max() <= TOL_DIST * scale
+        rho, kap = ref.viol_counts(b["pd"], b["nd"])             # counts are exact given the GPU's own distances
+        assert np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap)
+        if np.array_equal(rho, z["s%d_rho" % s]) and np.array_equal(kap, z["s%d_kappa" % s]):
+            assert relmax(ctx.dfavg(), z["s%d_dfavg" % s]) <= TOL_GRAD * 4
+            assert relmax(ctx.A(), z["s%d_A" % s]) <= TOL_A
+    ctx.close()
+
+
+def test_teacher_forced_live(dlco, ref):
+    """Same idea on a longer live trajectory with the reference's B = 200."""
+    N, F, B = 4000, 128, 200
+    D, L = synth(N, F, k=20, seed=9)
+    mu, gamma = 0.004, 0.5
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    checked = 0
+    for s in range(30):
+        before = tr.state()
+        tr.step()
+        after = tr.state()
+        ctx.set_state(s, before["dfavg"], before["W"] if s else None)
+        ctx.step()
+        b = ctx.batch()
+        pr, nr = tr.batch_ids()
+        assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+        pd, nd = tr.batch_dists()
+        scale = max(pd.max(), nd.max(), 1e-30)
+        assert np.abs(b["pd"] - pd).max() <= TOL_DIST * scale and np.abs(b["nd"] - nd).max() <= TOL_DIST * scale
+        rho, kap = ref.viol_counts(pd, nd)
+        if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
+            assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
+            assert relmax(ctx.A(), after["A"]) <= TOL_A
+            checked += 1
+    assert checked >= 20
+    ctx.close()
+    tr.close()
+
+
+def test_validation_and_stats(dlco, ref):
+    N, F, B = 6000, 64, 50
+    D, L = synth(N, F, k=10, seed=21, sp=0.7, noise=0.2)
+    mu, gamma = 0.004, 0.5
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    for _ in range(25):
+        tr.step()
+    st = tr.state()
+    ctx.set_state(st["t"] - 1, st["dfavg"], None)
+    # re-derive W on the GPU from the oracle's dual average (teacher forcing), then compare objectives
+    W, _ = ctx.psd_project(st["dfavg"], st["t"] - 1, want_A=False)
+    ctx.set_state(st["t"], st["dfavg"], W)
+    lo_ref, rg_ref = tr.validate()
+    dim_ref, f95_ref, auc_ref = tr.stats()
+    dim, f95, auc = ctx.stats(W)
+    assert abs(dim - dim_ref) <= 1
+    assert abs(f95 - f95_ref) <= 1e-3          # +-0.1 % absolute, the metric's stated band
+    assert abs(auc - auc_ref) <= 1e-3
+    d_all = ctx.project_sqdist(np.arange(N, dtype=np.int32), W)
+    f95b, aucb = ref.roc_stats(d_all, L)         # same distances -> identical ranking statistics
+    assert f95 == f95b and abs(auc - aucb) <= 1e-12
+    ctx.close()
+    tr.close()
+
+
+def test_end_to_end_trajectory_band(dlco, ref):
+    """Free-running GPU and oracle trainers: the trajectories are chaotic in the hinge mask, so
+    they are compared as the metric asks: objective, rank and FPR95 bands after the same steps."""
+    N, F, B = 6000, 64, 50
+    D, L = synth(N, F, k=10, seed=31, sp=0.7, noise=0.2)
+    mu, gamma = 0.004, 0.5
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    for _ in range(300):
+        tr.step()
+    ctx.steps(300)
+    lo, rg, rank = ctx.validate()
+    lo_r, rg_r = tr.validate()
+    _, f95, auc = ctx.stats()
+    dim_r, f95_r, auc_r = tr.stats()
+    assert abs(lo - lo_r) <= 0.05 * max(lo_r, 1e-6) + 1e-4
+    assert abs(rg - rg_r) <= 0.05 * max(rg_r, 1e-6) + 1e-4
+    assert abs(rank - dim_r) <= 2
+    assert abs(f95 - f95_r) <= 1e-3 and abs(auc - auc_r) <= 1e-3
+    e = ctx.log_step()
+    assert e.is_best == 1 and e.saved == 1 and e.t == 299
+    Ws, As = ctx.saved()
+    assert relmax(Ws.T.astype(np.float64) @ Ws.astype(np.float64), As) <= 1e-5
+    ctx.close()
+    tr.close()
+
+
+def test_full_width_properties(dlco):
+    """BASELINE shape in the feature dimension (F = 8192, B = 200) on a small row count:
+    size-independent invariants only (the oracle needs ~40 s per step at this width)."""
+    N, F, B = 4096, 8192, 200
+    ctx = dlco.Context(F, N, B=B, mu=0.002, gamma=0.5)
+    rng = np.random.default_rng(1)
+    U = np.linalg.qr(rng.standard_normal((F, 48)))[0].T.astype(np.float32)
+    ctx.synth_data(U, 99, 0.45, 1.0, 0.03)
+    ctx.steps(3)
+    b = ctx.batch()
+    assert (b["pd"] >= 0).all() and (b["nd"] >= 0).all() and b["rho"].sum() == b["kappa"].sum()
+    W = ctx.W()
+    assert 1 <= W.shape[0] < F
+    G = W.astype(np.float64) @ W.T.astype(np.float64)
+    n2 = np.diag(G)
+    assert np.abs(G - np.diag(n2)).max() <= 1e-4 * n2.max()       # rows orthogonal
+    assert (np.diff(n2) >= -1e-6 * n2.max()).all()                 # ascending eigenvalue order
+    df = ctx.dfavg()
+    assert np.array_equal(df, df.T)
+    rows = ctx.get_rows(0, 8)
+    assert np.abs(rows).max() <= 1.0
+    d = ctx.project_sqdist(np.arange(8, dtype=np.int32), W)
+    want = ((rows.astype(np.float64) @ W.T.astype(np.float64)) ** 2).sum(1)
+    assert np.abs(d - want).max() <= 1e-4 * want.max()
+    ctx.close()
