@@ -133,7 +133,7 @@ size_t jacobi_work_floats(int n);
 // row norms of (Y - theta_i X) and of X
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
-void row_normalize(float *X, long ld, int m, int F, hipStream_t s);
+void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);
 // y = H x style GEMV on a symmetric matrix (memory-bound), used by the spectral-bound estimator
 void symv(const float *H, long ld, int F, const float *x, float *y, hipStream_t s);
 // whitening coefficient matrix Cw[n][k] = U[:, keep] * lam^-1/2 for eigenvalues above thresh*lam_max; returns k on host

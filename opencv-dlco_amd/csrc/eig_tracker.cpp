@@ -148,22 +148,80 @@ int EigTracker::whiten(const float *src, int k, float *dst, bool *well_condition
     DLCO_HIP(hipStreamSynchronize(s_));
     const int kept = hi[0];
     st_.jacobi_sweeps += hi[1];
-    DLCO_CHECK(kept >= 1, -5, "eig tracker: basis collapsed during orthonormalisation");
+    if (kept < 1) { if (well_conditioned) *well_conditioned = true; return 0; }
     if (well_conditioned) *well_conditioned = pin_[8 + kept - 1] > 0.25f * pin_[8];
     rotate(Cw_.p, cap_, k, kept, src, dst);
     return kept;
 }
 
+// T[xrows][yrows] (ld cap_) = X * Y^T
+void EigTracker::gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T)
+{
+    GemmArgs g;
+    g.M = xrows; g.N = yrows; g.K = F_;
+    g.A.p = X; g.A.ld = F_; g.A.kmajor = false;
+    g.B.p = Y; g.B.ld = F_; g.B.kmajor = false;
+    g.C = T; g.ldc = cap_;
+    const long tiles = (long)ceil_div(xrows, xrows <= 64 ? 64 : 128) * ceil_div(yrows, yrows <= 64 ? 64 : 128);
+    long split = std::max(1L, std::min((long)ceil_div(512, tiles), (long)F_ / 64));
+    split = std::min(split, (long)(slab_floats_ / ((size_t)xrows * yrows)));
+    g.split_k = (int)std::max(1L, split);
+    g.slab = slab_.p;
+    gemm_f32(g, s_);
+}
+
+// Wp[np][F] -= (Wp Q^T) Q for the `kept` orthonormal rows of Q
+void EigTracker::project_out(float *Wp, int np, const float *Q, int kept)
+{
+    gram_rect(Wp, np, Q, kept, Cw_.p);
+    GemmArgs g;
+    g.M = np; g.N = F_; g.K = kept;
+    g.A.p = Cw_.p; g.A.ld = cap_; g.A.kmajor = false;
+    g.B.p = Q; g.B.ld = F_; g.B.kmajor = true;
+    g.C = Wp; g.ldc = F_;
+    g.alpha = -1.0f; g.beta = 1.0f;
+    gemm_f32(g, s_);
+}
+
 // Orthonormalise the rows of Z (clobbered) into `out`; returns the kept row count.
-int EigTracker::orthonormalize(float *Z, int rows, float *out)
+// Block Gram-Schmidt over panels of 32 rows: a panel is projected (twice) against the rows
+// already accepted, renormalised, then whitened by the eigendecomposition of its own Gram
+// matrix.  The rows arrive ordered by Ritz value, i.e. by how strongly the filter amplified
+// them, so every panel is internally well scaled even when the whole block spans a dynamic
+// range that a one-shot fp32 Gram matrix could not resolve.
+int EigTracker::orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends)
 {
     row_normalize(Z, F_, rows, F_, s_);
-    bool ok = false;
-    const int k1 = whiten(Z, rows, out, &ok);
-    if (ok) return k1;
-    const int k2 = whiten(out, k1, Z, nullptr);
-    DLCO_HIP(hipMemcpyAsync(out, Z, (size_t)k2 * F_ * sizeof(float), hipMemcpyDeviceToDevice, s_));
-    return k2;
+    int kept = 0;
+    // panel_ends: ascending row indices, last == rows.  Panels never mix rows of different
+    // provenance or of very different filter amplification (the caller decides the cuts).
+    size_t pi = 0;
+    for (int p0 = 0; p0 < rows;) {
+        while (pi < panel_ends.size() && panel_ends[pi] <= p0) pi++;
+        const int pend = pi < panel_ends.size() ? std::min(rows, panel_ends[pi]) : rows;
+        const int np = pend - p0;
+        float *Wp = Z + (size_t)p0 * F_;
+        if (kept > 0) {
+            for (int pass = 0; pass < 2; pass++) {
+                project_out(Wp, np, out, kept);
+                // after the first projection, rows that lie (to fp32 accuracy) inside the accepted span are zeroed
+                row_normalize(Wp, F_, np, F_, s_, pass == 0 ? 2e-5f : 0.f);
+            }
+        }
+        float *dst = out + (size_t)kept * F_;
+        bool ok = false;
+        int k = whiten(Wp, np, dst, &ok);
+        if (!ok && k > 0) {
+            const int k2 = whiten(dst, k, Wp, nullptr);
+            DLCO_HIP(hipMemcpyAsync(dst, Wp, (size_t)k2 * F_ * sizeof(float), hipMemcpyDeviceToDevice, s_));
+            k = k2;
+        }
+        kept += k;
+        p0 = pend;
+        if (kept >= F_) { kept = F_; break; }
+    }
+    DLCO_CHECK(kept >= 1, -5, "eig tracker: basis collapsed during orthonormalisation");
+    return kept;
 }
 
 // Power iteration for lambda_max(G); the lower end of H = -G is -lambda_max(G).
@@ -220,9 +278,14 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
 
     bool conv = false;
     int nw = 0, it = 0;
+    int n_ritz = have_theta_ ? m_ : 0;        // leading rows that are Ritz vectors with a known theta
+    std::vector<int> panel_ends;
     for (; it < max_iter_; it++) {
         float *Z = Q_;
-        if (m_ < F_) {
+        panel_ends.clear();
+        // The filter is only applied to a block of Ritz vectors (theta known): the amplification of
+        // each row is then predictable and the panels of the orthonormalisation can follow it.
+        if (m_ < F_ && n_ritz > 0) {
             // ---- Chebyshev filter of degree d damping [a, b] of H = -G ---------------------------
             const float a = lo_bound_;
             float b = std::min(block_min, mu);
@@ -231,7 +294,9 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             const float c0 = 0.5f * (a + b), e0 = 0.5f * (b - a);
             int d = it == 0 ? 4 : (it == 1 ? 6 : (it < 4 ? 8 : 10));
             const float xmax = std::max(1.5f, (std::max(theta_top, mu) - c0) / e0);
-            const int dcap = (int)(28.0f / std::log10(2.0f * xmax));       // keep T_d(xmax) inside fp32
+            // keep the top/guard amplification ratio T_d(xmax) below ~1e5: the guard rows survive the
+            // cancellation against the amplified rows with ~1e5 * 6e-8 relative noise
+            const int dcap = (int)(12.2f / std::acosh(xmax));
             d = std::max(2, std::min(d, dcap));
             const float *prev = Q_;
             float *cur = pick({Q_});
@@ -242,10 +307,22 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                 prev = cur; cur = nxt;
             }
             Z = cur;
+            // panels: at most 32 rows, predicted amplification T_d(x_j) within a factor 30 inside a panel
+            int start = 0;
+            double amp0 = 0.0;
+            for (int j = 0; j < n_ritz; j++) {
+                const double x = std::max(1.0, (double)(h_theta_[j] - c0) / e0);
+                const double amp = std::cosh((double)d * std::acosh(x));
+                if (j == start) amp0 = amp;
+                else if (j - start >= 32 || amp0 > 30.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
+            }
+            if (n_ritz < m_) panel_ends.push_back(n_ritz);
         }
+        for (int j = (panel_ends.empty() ? 0 : panel_ends.back()) + 32; j < m_; j += 32) panel_ends.push_back(j);
+        panel_ends.push_back(m_);
         // ---- orthonormalise, Rayleigh-Ritz -------------------------------------------------------
         float *Qo = pick({Z});
-        m_ = orthonormalize(Z, m_, Qo);
+        m_ = orthonormalize(Z, m_, Qo, panel_ends);
         float *Yb = pick({Qo});
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f);            // Yb = Qo * H
         gram(Yb, Qo, m_, Tm_.p);
@@ -267,15 +344,28 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         theta_top = h_theta_[0];
         block_min = std::min(h_theta_[m_ - 1], mu);
 
+        n_ritz = m_;
         nw = 0;
         while (nw < m_ && h_theta_[nw] > mu) nw++;
         float crit = 0.f;
         for (int i = 0; i < nw; i++) crit = std::max(crit, cscale * h_res_[i]);
         const float emax = nw > 0 ? cscale * (h_theta_[0] - mu) : 0.f;
         last_crit_ = emax > 0.f ? crit / emax : 0.f;
+        // the leading guards must be resolved too, or an eigenvalue just above mu can hide in them:
+        // each needs theta + |r| < mu (no eigenvalue of that pair's interval reaches mu) or a small residual
+        bool guards_ok = true;
+        const int ng = std::min(m_, nw + std::max(2, guard_ / 4));
+        for (int i = nw; i < ng; i++) {
+            const bool below = h_theta_[i] + h_res_[i] < mu;
+            const bool small = cscale * h_res_[i] <= tol_ * std::max(emax, cscale * 1e-3f * std::fabs(mu));
+            guards_ok = guards_ok && (below || small);
+        }
         if (m_ >= F_) conv = true;                                   // dense: Rayleigh-Ritz is exact
-        else if (nw == 0) conv = (h_theta_[0] + h_res_[0] < mu) || it >= 2;
-        else conv = crit <= tol_ * emax;
+        else if (nw == 0) conv = guards_ok || it >= 6;
+        else conv = crit <= tol_ * emax && guards_ok;
+        if (debug_)
+            std::fprintf(stderr, "[eig] upd %ld it %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g conv %d\n",
+                         (long)st_.updates, it, m_, nw, h_theta_[0], h_theta_[m_ - 1], mu, lo_bound_, last_crit_, (int)conv);
         if (h_theta_[m_ - 1] < lo_bound_) lo_bound_ = h_theta_[m_ - 1] - 0.5f * std::fabs(h_theta_[m_ - 1]) - 1e-12f;
         // ---- grow the block when the positive eigenspace reaches into the guard ------------------
         if (m_ < F_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {

@@ -44,9 +44,11 @@ private:
     void product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
                  const float *E2, float b2);
     void gram(const float *X, const float *Y, int rows, float *T);
+    void gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T);
+    void project_out(float *Wp, int np, const float *Q, int kept);
     void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out);
     int whiten(const float *src, int k, float *dst, bool *well_conditioned);
-    int orthonormalize(float *Z, int rows, float *out);          // returns kept rows
+    int orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends);   // returns kept rows
     void refresh_lower_bound(const float *G, int iters, float theta_top);
     void append_random(float *Q, int have, int add);
     float next_uniform();
@@ -62,6 +64,7 @@ private:
     int steps_since_lo_ = 0;
     uint64_t rng_ = 0x243F6A8885A308D3ULL;
     float last_crit_ = 0.f;
+    bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
 
     DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F
     float *all_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

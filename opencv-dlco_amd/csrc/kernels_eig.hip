@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void residual_kernel(const float *X, const flo
     if (threadIdx.x == 0) res[i] = sqrtf(part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ __launch_bounds__(256) void row_normalize_kernel(float *X, long ld, int m, int F)
+// rows whose norm is below `min_norm` are zeroed (dependent directions), the rest scaled to unit norm
+__global__ __launch_bounds__(256) void row_normalize_kernel(float *X, long ld, int m, int F, float min_norm)
 {
     __shared__ float part[4];
     __shared__ float inv;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(float *X, long ld, i
     s = wsum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { const float n2 = part[0] + part[1] + part[2] + part[3]; inv = n2 > 0.f ? 1.f / sqrtf(n2) : 0.f; }
+    if (threadIdx.x == 0) { const float n2 = part[0] + part[1] + part[2] + part[3]; inv = (n2 > 0.f && n2 >= min_norm * min_norm) ? 1.f / sqrtf(n2) : 0.f; }
     __syncthreads();
     const float sc = inv;
     for (int f = threadIdx.x; f < F; f += blockDim.x) X[(long)i * ld + f] *= sc;
@@ -246,10 +247,10 @@ void residual_norms(const float *X, const float *Y, long ld, const float *theta,
     DLCO_HIP(hipGetLastError());
 }
 
-void row_normalize(float *X, long ld, int m, int F, hipStream_t s)
+void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm)
 {
     if (m <= 0) return;
-    hipLaunchKernelGGL(row_normalize_kernel, dim3(m), dim3(256), 0, s, X, ld, m, F);
+    hipLaunchKernelGGL(row_normalize_kernel, dim3(m), dim3(256), 0, s, X, ld, m, F, min_norm);
     DLCO_HIP(hipGetLastError());
 }
 
