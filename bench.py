@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — pj-learn patch-pairs/sec on the BASELINE workload (config[1]):
+Liberty-shaped 500k labelled pair-rows x PR-dim 8192, batch 200 positives + 200 negatives
+per GPU, fp32, learned rank ~64.  Synthetic data of that shape is generated in HBM (the
+Brown/Winder sets are not redistributable and there is no network).
+
+A "step" is one full iteration of the reference's training loop (src/pj-learn.cpp:305-490):
+sample the batch, project + squared distances, violation counts, fused weighted-SYRK
+gradient + dual average, PSD projection.  Nothing is skipped inside the timed region.
+
+    python bench.py --gpus 1 --steps 40 --warmup 10
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (dense)
+
+
+def make_U(F, k, seed):
+    """Latent directions with decaying strength so that the trace-norm threshold mu selects a rank."""
+    rng = np.random.default_rng(seed)
+    U = rng.standard_normal((k, F)).astype(np.float32)
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    decay = (1.0 / (1.0 + np.arange(k) / 24.0)).astype(np.float32)
+    return (U * decay[:, None]).astype(np.float32)
+
+
+def cpu_baseline(ctx, F, B, mu, gamma, rows):
+    """The oracle (reference loop order, OpenBLAS sgemm/ssyevr) timed on this box's host cores
+    on a bounded sample: one full training step on a `rows`-row subset of the same data."""
+    from oracle import ref
+
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ref.lib()
+    kind = ref.blas_kind()
+    if kind != "openblas":
+        return {"value": None, "unit": "pair-rows/s", "cores": ncores, "kind": "port",
+                "sample": "skipped: no OpenBLAS found for the oracle's ssyevr at F=%d" % F}
+    ref.set_threads(ncores)
+    D = ctx.get_rows(0, rows)
+    L = (np.arange(rows) % 2 == 0).astype(np.uint8)
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=0)
+    t0 = time.perf_counter()
+    tr.step()
+    dt = time.perf_counter() - t0
+    tr.close()
+    return {"value": 2.0 * B / dt, "unit": "pair-rows/s", "cores": ncores, "kind": "port",
+            "sample": "1 full step (t=0, reference loop order, OpenBLAS sgemm+ssyevr) at F=%d B=%d on a %d-row subset of the same synthetic data, %.1f s"
+                      % (F, B, rows, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--F", type=int, default=8192)
+    ap.add_argument("--N", type=int, default=500000)
+    ap.add_argument("--batch", type=int, default=200, help="pair-rows per class PER GPU")
+    ap.add_argument("--mu", type=float, default=0.01)
+    ap.add_argument("--gamma", type=float, default=0.5)
+    ap.add_argument("--latent", type=int, default=96)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=4096)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N > 1" % (args.gpus, world), file=sys.stderr)
+        if args.gpus > 1:
+            sys.exit(2)
+
+    dlco = importlib.import_module("opencv-dlco_amd")
+    F, N, Bl = args.F, args.N, args.batch
+    B = Bl * world
+
+    trainer = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ddist = importlib.import_module("opencv-dlco_amd.dist")
+    ctx = dlco.Context(F, N, B=B, mu=args.mu, gamma=args.gamma, device=local_rank, rank=rank, world=world)
+    dev_name, _, _ = ctx.device_name()
+    U = make_U(F, args.latent, 2215 + 1)
+    ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)        # identical bytes on every rank (dataset replicated)
+    if world > 1:
+        engine = ddist.HipEngine(dlco, ctx, torch.device("cuda", local_rank))
+        trainer = ddist.DataParallelTrainer(engine)
+
+    def run(n):
+        if trainer is None:
+            ctx.steps(n)
+        else:
+            trainer.steps(n)
+
+    def barrier():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    ctx.profile_enable(True)
+    es0 = ctx.eig_stats()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    es1 = ctx.eig_stats()
+    n_syrk, ms_syrk = ctx.profile_read("grad_syrk")
+    n_prod, ms_prod = ctx.profile_read("eig_product")
+    n_jac, ms_jac = ctx.profile_read("jacobi")
+    n_prj, ms_prj = ctx.profile_read("project")
+    ctx.profile_enable(False)
+
+    rank_now = ctx.W().shape[0]
+    value = 2.0 * B * args.steps / dt
+    # dominant kernel of the hot path: the fused weighted-SYRK gradient + dual average.
+    # algorithmic flops per launch (dense, no symmetry credit): 2 * (2*Bl) * F^2
+    flops_launch = 4.0 * Bl * F * F
+    ach = flops_launch / (ms_syrk / max(n_syrk, 1) * 1e-3) / 1e12 if n_syrk else None
+    out = {
+        "metric": "pj-learn patch-pairs/sec",
+        "value": value,
+        "unit": "pair-rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "pj-learn Liberty-shaped %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
+                        % (N, F, Bl, Bl, B, B, args.mu, args.gamma, rank_now, args.warmup + args.steps),
+            "device": dev_name,
+            "parallelism": "dp%d (replicated data, batch slots sharded, all-gather dists + all-reduce gradient)" % world,
+            "combinations_per_s": float(B) * B * args.steps / dt,
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "grad_syrk_rda (fused weighted SYRK + dual average)",
+            "achieved": ach,
+            "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
+            "traffic": None,
+            "avg_launch_ms": ms_syrk / max(n_syrk, 1),
+            "launches": n_syrk,
+            "algorithmic_flops_per_launch": flops_launch,
+        },
+        "breakdown_ms_per_step": {
+            "grad_syrk": ms_syrk / args.steps,
+            "eig_products": ms_prod / args.steps,
+            "eig_jacobi": ms_jac / args.steps,
+            "project": ms_prj / args.steps,
+            "eig_iters_per_step": (es1["iters"] - es0["iters"]) / args.steps,
+            "eig_product_rows_per_step": (es1["product_rows"] - es0["product_rows"]) / args.steps,
+            "eig_block_rows": es1["block_rows"],
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, F, Bl, args.mu, args.gamma, args.cpu_rows)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,10 @@ int dlco_step_finish(dlco_ctx *ctx);
 #define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
 /* Device pointer and byte size of an exchange buffer (valid until ctx is destroyed). */
 int dlco_dev_buffer(dlco_ctx *ctx, int32_t which, void **dev_ptr, size_t *bytes);
+/* Makes the context use caller-owned device memory for an exchange buffer (DLCO_BUF_DIST or
+ * DLCO_BUF_GRAD), e.g. a tensor the caller's RCCL communicator operates on.  The memory
+ * must outlive the context. */
+int dlco_bind_buffer(dlco_ctx *ctx, int32_t which, void *dev_ptr, size_t bytes);
 /* The HIP stream the context launches on (as void*), so callers can order collectives. */
 int dlco_stream(dlco_ctx *ctx, void **stream);
 int dlco_sync(dlco_ctx *ctx);

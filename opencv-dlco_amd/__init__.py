@@ -88,6 +88,7 @@ def load():
         getattr(L, name).argtypes = [vp]
     L.dlco_steps.argtypes = [vp, C.c_int32]
     L.dlco_dev_buffer.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.dlco_bind_buffer.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.dlco_stream.argtypes = [vp, C.POINTER(vp)]
     L.dlco_get_batch.argtypes = [vp, i32p, i32p, f32p, f32p, i32p, i32p]
     L.dlco_get_t.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -225,6 +226,9 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         self._ck(self.L.dlco_dev_buffer(self.h, which, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def bind_buffer(self, which, dev_ptr, nbytes):
+        self._ck(self.L.dlco_bind_buffer(self.h, which, C.c_void_p(dev_ptr), nbytes))
 
     def stream(self):
         p = C.c_void_p()

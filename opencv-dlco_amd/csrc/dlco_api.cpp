@@ -42,6 +42,7 @@ struct dlco_ctx {
     std::vector<int32_t> h_pos_rows, h_neg_rows;
     DevBuf<int32_t> pos_rows, neg_rows, local_ids, rho, kappa, act_ids, seed_ids;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
+    float *xdist = nullptr, *xgrad = nullptr;   // exchange buffers (own allocations unless bound by the caller)
     DevBuf<int> k_active;
     DevBuf<double> dscal;
     size_t proj_slab_floats = 0;
@@ -57,12 +58,8 @@ struct dlco_ctx {
     std::vector<float> W_save, A_save;
     int r_save = 0;
 
-    // profiling of the gradient SYRK
-    bool prof = false;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    double prof_ms = 0.0;
-    int64_t prof_n = 0;
+    // HIP-event timers (gradient SYRK, tracker products, ...)
+    Profiler prof;
 };
 
 namespace {
@@ -154,31 +151,10 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
     g.split_k = (int)split; g.slab = c->proj_slab.p; g.raw_slab = true;
     int used = 1;
     g.split_out = &used;
+    c->prof.begin(PROF_PROJECT);
     gemm_f32(g, c->stream);
     sqdist_from_proj(c->proj_slab.p, used, r, n, n, out_dev, c->stream);
-}
-
-hipEvent_t next_event(dlco_ctx *c)
-{
-    if (c->ev_used == c->ev_pool.size()) {
-        hipEvent_t e;
-        DLCO_HIP(hipEventCreate(&e));
-        c->ev_pool.push_back(e);
-    }
-    return c->ev_pool[c->ev_used++];
-}
-
-void drain_events(dlco_ctx *c)
-{
-    if (c->ev_used == 0) return;
-    sync(c);
-    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-        float ms = 0.f;
-        DLCO_HIP(hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
-        c->prof_ms += ms;
-        c->prof_n++;
-    }
-    c->ev_used = 0;
+    c->prof.end(PROF_PROJECT);
 }
 
 // dst = beta*dst_in + alpha * X^T diag(w) X over the active rows (upper triangle computed, mirrored)
@@ -193,15 +169,9 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
     g.alpha = alpha; g.beta = beta;
     g.k_dev = k_dev;
     g.upper_only = true;
-    if (c->prof) {
-        if (c->ev_used + 2 > 4096) drain_events(c);
-        hipEvent_t e0 = next_event(c), e1 = next_event(c);
-        DLCO_HIP(hipEventRecord(e0, c->stream));
-        gemm_f32(g, c->stream);
-        DLCO_HIP(hipEventRecord(e1, c->stream));
-    } else {
-        gemm_f32(g, c->stream);
-    }
+    c->prof.begin(PROF_GRAD_SYRK);
+    gemm_f32(g, c->stream);
+    c->prof.end(PROF_GRAD_SYRK);
 }
 
 void rda_coeffs(const dlco_ctx *c, float *alpha, float *beta)
@@ -231,7 +201,7 @@ void step_begin(dlco_ctx *c)
     DLCO_HIP(hipMemcpyAsync(c->local_ids.p + Bl, c->h_neg_rows.data() + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     sync(c);   // host vectors are reused next step
     // P1+P2 on this rank's slots -> its slice of the exchange buffer
-    project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->dist_x.p + (size_t)c->cfg.rank * 2 * Bl);
+    project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl);
     c->phase = 1;
 }
 
@@ -240,9 +210,9 @@ void step_grad(dlco_ctx *c)
     DLCO_CHECK(c->phase == 1, DLCO_ERR_INVALID, "dlco_step_grad: call dlco_step_begin first");
     const int B = c->B, Bl = c->Bl, world = c->cfg.world;
     for (int g = 0; g < world; g++) {
-        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->dist_x.p + (size_t)g * 2 * Bl, Bl * sizeof(float),
+        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
                                 hipMemcpyDeviceToDevice, c->stream));
-        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->dist_x.p + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
+        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
                                 hipMemcpyDeviceToDevice, c->stream));
     }
     viol_counts(c->pd.p, c->nd.p, B, c->rho.p, c->kappa.p, c->stream);
@@ -251,7 +221,7 @@ void step_grad(dlco_ctx *c)
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
     if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p);
-    else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->grad.p);
+    else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->xgrad);
     c->phase = 2;
 }
 
@@ -261,7 +231,7 @@ void step_finish(dlco_ctx *c)
     if (c->cfg.world > 1) {
         float alpha, beta;
         rda_coeffs(c, &alpha, &beta);
-        axpby_inplace(c->dfavg.p, c->grad.p, beta, alpha, (size_t)c->F * c->F, c->stream);
+        axpby_inplace(c->dfavg.p, c->xgrad, beta, alpha, (size_t)c->F * c->F, c->stream);
     }
     // E1/E2.  Cold tracker: the range of dfAvg after the first step is spanned by the batch rows,
     // so they seed the block (global batch: every rank holds the full row lists and counts).
@@ -374,11 +344,13 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->Bl = cfg->B / cfg->world; c->lo = cfg->rank * c->Bl;
         c->rng = CvRng(cfg->seed);
         DLCO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->prof.s = c->stream;
         const size_t FF = (size_t)c->F * c->F;
         c->dfavg.alloc(FF); c->dfavg.zero(c->stream);
         c->grad.alloc(FF);
         const int max_rows = std::max(1024, 2 * c->B + c->cfg.eig_guard);
         c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
+        c->eig->set_profiler(&c->prof);
         c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
         c->W.alloc((size_t)c->w_cap * c->F);
         const int B = c->B;
@@ -387,6 +359,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->rho.alloc(B); c->kappa.alloc(B);
         c->act_ids.alloc(2 * B); c->act_w.alloc(2 * B); c->seed_ids.alloc(2 * B); c->seed_w.alloc(2 * B);
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
+        c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
         c->dscal.alloc(4);
         sync(c);
@@ -403,7 +376,6 @@ void dlco_ctx_destroy(dlco_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->eig;
     if (c->roc) roc_work_destroy(c->roc);
-    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -508,12 +480,29 @@ int dlco_dev_buffer(dlco_ctx *c, int32_t which, void **dev_ptr, size_t *bytes)
     if (!c || !dev_ptr || !bytes) return DLCO_ERR_INVALID;
     const size_t FF = (size_t)c->F * c->F * sizeof(float);
     switch (which) {
-    case DLCO_BUF_DIST: *dev_ptr = c->dist_x.p; *bytes = (size_t)2 * c->B * sizeof(float); return DLCO_OK;
-    case DLCO_BUF_GRAD: *dev_ptr = c->grad.p; *bytes = FF; return DLCO_OK;
+    case DLCO_BUF_DIST: *dev_ptr = c->xdist; *bytes = (size_t)2 * c->B * sizeof(float); return DLCO_OK;
+    case DLCO_BUF_GRAD: *dev_ptr = c->xgrad; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_DFAVG: *dev_ptr = c->dfavg.p; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_W: *dev_ptr = c->W.p; *bytes = (size_t)c->r * c->F * sizeof(float); return DLCO_OK;
     default: return DLCO_ERR_INVALID;
     }
+}
+
+int dlco_bind_buffer(dlco_ctx *c, int32_t which, void *dev_ptr, size_t bytes)
+{
+    if (!c || !dev_ptr) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_bind_buffer: step in flight");
+        if (which == DLCO_BUF_DIST) {
+            DLCO_CHECK(bytes >= (size_t)2 * c->B * sizeof(float), DLCO_ERR_INVALID, "dlco_bind_buffer: DIST buffer too small");
+            c->xdist = static_cast<float *>(dev_ptr);
+        } else if (which == DLCO_BUF_GRAD) {
+            DLCO_CHECK(bytes >= (size_t)c->F * c->F * sizeof(float), DLCO_ERR_INVALID, "dlco_bind_buffer: GRAD buffer too small");
+            c->xgrad = static_cast<float *>(dev_ptr);
+        } else {
+            throw Error(DLCO_ERR_INVALID, "dlco_bind_buffer: only DLCO_BUF_DIST and DLCO_BUF_GRAD can be bound");
+        }
+    });
 }
 
 int dlco_stream(dlco_ctx *c, void **stream)
@@ -797,20 +786,23 @@ int dlco_profile_enable(dlco_ctx *c, int32_t on)
 {
     if (!c) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
-        drain_events(c);
-        c->prof = on != 0;
-        if (on) { c->prof_ms = 0.0; c->prof_n = 0; }
+        c->prof.reset();
+        c->prof.on = on != 0;
     });
 }
 
 int dlco_profile_read(dlco_ctx *c, const char *kernel, int64_t *launches, double *total_ms)
 {
     if (!c || !launches || !total_ms) return DLCO_ERR_INVALID;
-    (void)kernel;
     return guarded(c, [&] {
-        drain_events(c);
-        *launches = c->prof_n;
-        *total_ms = c->prof_ms;
+        int slot = PROF_GRAD_SYRK;
+        if (kernel && std::strcmp(kernel, "eig_product") == 0) slot = PROF_EIG_PRODUCT;
+        else if (kernel && std::strcmp(kernel, "jacobi") == 0) slot = PROF_JACOBI;
+        else if (kernel && std::strcmp(kernel, "project") == 0) slot = PROF_PROJECT;
+        else if (kernel && std::strcmp(kernel, "grad_syrk") != 0) throw Error(DLCO_ERR_INVALID, "dlco_profile_read: unknown kernel group");
+        c->prof.drain(slot);
+        *launches = c->prof.rec[slot].n;
+        *total_ms = c->prof.rec[slot].ms;
     });
 }
 

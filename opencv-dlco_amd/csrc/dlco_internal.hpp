@@ -58,6 +58,41 @@ struct DevBuf {
 };
 
 // ---------------------------------------------------------------------------
+// HIP-event timers on the launch stream, one slot per named kernel group
+// ---------------------------------------------------------------------------
+enum ProfSlot { PROF_GRAD_SYRK = 0, PROF_EIG_PRODUCT = 1, PROF_JACOBI = 2, PROF_PROJECT = 3, PROF_SLOTS = 4 };
+
+struct Profiler {
+    bool on = false;
+    hipStream_t s = nullptr;
+    struct Rec { std::vector<hipEvent_t> ev; size_t used = 0; double ms = 0.0; int64_t n = 0; };
+    Rec rec[PROF_SLOTS];
+    ~Profiler() { for (auto &r : rec) for (hipEvent_t e : r.ev) (void)hipEventDestroy(e); }
+    void mark(int slot) {
+        if (!on) return;
+        Rec &r = rec[slot];
+        if (r.used == r.ev.size()) { hipEvent_t e; DLCO_HIP(hipEventCreate(&e)); r.ev.push_back(e); }
+        DLCO_HIP(hipEventRecord(r.ev[r.used++], s));
+        if (r.used >= 8192 && (r.used % 2) == 0) drain(slot);
+    }
+    void begin(int slot) { mark(slot); }
+    void end(int slot) { mark(slot); }
+    void drain(int slot) {
+        Rec &r = rec[slot];
+        if (r.used == 0) return;
+        DLCO_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i + 1 < r.used; i += 2) {
+            float ms = 0.f;
+            DLCO_HIP(hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]));
+            r.ms += ms; r.n++;
+        }
+        r.used = 0;
+    }
+    void drain_all() { for (int i = 0; i < PROF_SLOTS; i++) drain(i); }
+    void reset() { drain_all(); for (auto &r : rec) { r.ms = 0.0; r.n = 0; } }
+};
+
+// ---------------------------------------------------------------------------
 // generic fp32 MFMA GEMM (kernels_gemm.hip)
 //   C[M,N] = alpha * A(M,K) * B(K,N)  (+ epilogue)
 // Operand addressing:

@@ -103,7 +103,9 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     split = std::min(split, (long)(slab_floats_ / ((size_t)rows * F_)));
     g.split_k = (int)std::max(1L, split);
     g.slab = slab_.p;
+    if (prof_) prof_->begin(PROF_EIG_PRODUCT);
     gemm_f32(g, s_);
+    if (prof_) prof_->end(PROF_EIG_PRODUCT);
     st_.product_rows += rows;
 }
 
@@ -140,7 +142,9 @@ void EigTracker::rotate(const float *C, long ldc, int k_in, int k_out, const flo
 int EigTracker::whiten(const float *src, int k, float *dst, bool *well_conditioned)
 {
     gram(src, src, k, Tm_.p);
+    if (prof_) prof_->begin(PROF_JACOBI);
     jacobi_eigh(Tm_.p, cap_, k, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
+    if (prof_) prof_->end(PROF_JACOBI);
     build_whitener(evals_.p, Vm_.p, cap_, k, 1e-6f, Cw_.p, cap_, ibuf_.p, s_);
     int *hi = reinterpret_cast<int *>(pin_);
     DLCO_HIP(hipMemcpyAsync(hi, ibuf_.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s_));
@@ -326,7 +330,9 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         float *Yb = pick({Qo});
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f);            // Yb = Qo * H
         gram(Yb, Qo, m_, Tm_.p);
+        if (prof_) prof_->begin(PROF_JACOBI);
         jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
+        if (prof_) prof_->end(PROF_JACOBI);
         float *Qn = pick({Qo, Yb});
         rotate(Vm_.p, cap_, m_, m_, Qo, Qn);
         float *Yn = pick({Qo, Yb, Qn});

@@ -37,6 +37,7 @@ public:
     int update(const float *G, float mu, float cscale, float *W, double *trace, bool *converged);
 
     int block_rows() const { return m_; }
+    void set_profiler(Profiler *p) { prof_ = p; }
     const EigStats &stats() const { return st_; }
     float last_crit() const { return last_crit_; }
 
@@ -78,6 +79,7 @@ private:
     float *pin_ = nullptr;           // pinned host staging
     size_t pin_floats_ = 0;
     EigStats st_;
+    Profiler *prof_ = nullptr;
 };
 
 }  // namespace dlco

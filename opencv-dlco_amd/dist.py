@@ -1,0 +1,71 @@
+"""Data-parallel pj-learn over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+One process per GPU.  The global batch of B positive and B negative pair-rows is sampled
+identically on every rank (same cv::RNG stream); rank g owns the batch slots
+[g*B/G, (g+1)*B/G).  Per step there are exactly two exchanges:
+
+    begin  : project the rank's slots                     -> its slice of DIST  [G][2B/G] f32
+    all_gather(DIST)                                       (1.6 kB at B = 200)
+    grad   : global violation counts, the rank's partial   -> GRAD [F,F] f32
+             gradient P^T diag(rho) P - N^T diag(kappa) N
+    all_reduce(GRAD, SUM)                                  (268 MB at F = 8192)
+    finish : dual average + PSD projection, replicated
+
+The trainer below is backend-agnostic: `engine` is any object with the three phase methods
+and two torch tensors (`dist`, `grad`) that alias its exchange buffers.  The product engine
+is HipEngine (libdlco.so); the CPU tests drive the same class with an oracle-backed engine
+over gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipEngine:
+    """libdlco.so context whose exchange buffers are torch tensors (so RCCL can move them)."""
+
+    def __init__(self, dlco, ctx, device):
+        self.dlco, self.ctx = dlco, ctx
+        B, F = ctx.B, ctx.F
+        self.dist = torch.zeros(2 * B, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(F * F, dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        ctx.bind_buffer(dlco.BUF_DIST, self.dist.data_ptr(), self.dist.numel() * 4)
+        ctx.bind_buffer(dlco.BUF_GRAD, self.grad.data_ptr(), self.grad.numel() * 4)
+        self.device = device
+
+    def begin(self):
+        self.ctx.step_begin()
+        self.ctx.sync()                 # library stream -> visible to torch's stream
+
+    def grad_phase(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.step_grad()
+        self.ctx.sync()
+
+    def finish(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.step_finish()
+
+
+class DataParallelTrainer:
+    def __init__(self, engine, group=None):
+        self.e = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def step(self):
+        e = self.e
+        e.begin()
+        if self.world > 1:
+            per = e.dist.numel() // self.world
+            mine = e.dist[self.rank * per:(self.rank + 1) * per]
+            dist.all_gather_into_tensor(e.dist, mine.clone(), group=self.group)
+        e.grad_phase()
+        if self.world > 1:
+            dist.all_reduce(e.grad, op=dist.ReduceOp.SUM, group=self.group)
+        e.finish()
+
+    def steps(self, n):
+        for _ in range(n):
+            self.step()
