@@ -186,6 +186,7 @@ def main():
             "eig_jacobi": ms_jac / args.steps,
             "project": ms_prj / args.steps,
             "eig_iters_per_step": (es1["iters"] - es0["iters"]) / args.steps,
+            "eig_jacobi_sweeps_per_step": (es1["jacobi_sweeps"] - es0["jacobi_sweeps"]) / args.steps,
             "eig_product_rows_per_step": (es1["product_rows"] - es0["product_rows"]) / args.steps,
             "eig_block_rows": es1["block_rows"],
         },

@@ -141,19 +141,19 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
     const int bm = r <= 64 ? 64 : 128, bn = n <= 64 ? 64 : 128;
     const long tiles = (long)((r + bm - 1) / bm) * ((n + bn - 1) / bn);
-    long split = std::max(1L, std::min((1024 + tiles - 1) / tiles, (long)c->F / 64));
-    const size_t need = (size_t)split * r * n;
+    long split = std::max(1L, std::min((512 + tiles - 1) / tiles, (long)c->F / 128));
+    const size_t need = (size_t)(split + 1) * r * n;
     if (need > c->proj_slab_floats) { c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+    float *proj = c->proj_slab.p + (size_t)split * r * n;       // reduced [r][n] projection behind the slabs
     GemmArgs g;
     g.M = r; g.N = n; g.K = c->F;
     g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
     g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = false; g.B.row_ids = ids_dev;
-    g.split_k = (int)split; g.slab = c->proj_slab.p; g.raw_slab = true;
-    int used = 1;
-    g.split_out = &used;
+    g.C = proj; g.ldc = n;
+    g.split_k = (int)split; g.slab = c->proj_slab.p;
     c->prof.begin(PROF_PROJECT);
-    gemm_f32(g, c->stream);
-    sqdist_from_proj(c->proj_slab.p, used, r, n, n, out_dev, c->stream);
+    gemm_f32(g, c->stream);                                      // slabs summed in slice order: deterministic
+    sqdist_from_proj(proj, 1, r, n, n, out_dev, c->stream);
     c->prof.end(PROF_PROJECT);
 }
 
@@ -161,6 +161,14 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
 void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev, int kmax, float alpha, float beta,
                float *dst)
 {
+    // fused, symmetric, branch-free kernel when the shape allows it (F a multiple of 128)
+    if (c->F % 128 == 0 && (reinterpret_cast<uintptr_t>(c->dists) & 15) == 0) {
+        c->prof.begin(PROF_GRAD_SYRK);
+        const bool done = syrk_rda_f32(c->dists, c->F, ids, w, k_dev, (kmax + 31) & ~31, c->F, alpha, beta, dst, c->F, c->stream);
+        c->prof.end(PROF_GRAD_SYRK);
+        DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
+        return;
+    }
     GemmArgs g;
     g.M = c->F; g.N = c->F; g.K = kmax;
     g.A.p = c->dists; g.A.ld = c->F; g.A.kmajor = true; g.A.row_ids = ids; g.A.row_scale = w;
@@ -357,7 +365,8 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
         c->pos_rows.alloc(B); c->neg_rows.alloc(B); c->local_ids.alloc(2 * c->Bl);
         c->rho.alloc(B); c->kappa.alloc(B);
-        c->act_ids.alloc(2 * B); c->act_w.alloc(2 * B); c->seed_ids.alloc(2 * B); c->seed_w.alloc(2 * B);
+        const int kcap = (2 * B + 31) & ~31;                      // row lists are zero padded to whole K tiles
+        c->act_ids.alloc(kcap); c->act_w.alloc(kcap); c->seed_ids.alloc(kcap); c->seed_w.alloc(kcap);
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
@@ -651,7 +660,7 @@ int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_
             DLCO_CHECK(pos_rows_host[i] >= 0 && pos_rows_host[i] < c->N && neg_rows_host[i] >= 0 && neg_rows_host[i] < c->N,
                        DLCO_ERR_INVALID, "dlco_grad_rda: row id out of range");
         DevBuf<int32_t> pr, nr, rho, kap, ids; DevBuf<float> w; DevBuf<int> k;
-        pr.alloc(B); nr.alloc(B); rho.alloc(B); kap.alloc(B); ids.alloc(2 * B); w.alloc(2 * B); k.alloc(1);
+        pr.alloc(B); nr.alloc(B); rho.alloc(B); kap.alloc(B); ids.alloc((2 * B + 31) & ~31); w.alloc((2 * B + 31) & ~31); k.alloc(1);
         h2d(c, pr.p, pos_rows_host, (size_t)B * sizeof(int32_t));
         h2d(c, nr.p, neg_rows_host, (size_t)B * sizeof(int32_t));
         h2d(c, rho.p, rho_host, (size_t)B * sizeof(int32_t));

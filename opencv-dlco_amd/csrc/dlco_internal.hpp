@@ -130,6 +130,15 @@ struct GemmArgs {
 };
 
 void gemm_f32(const GemmArgs &a, hipStream_t s);
+// Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
+// rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
+// zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).
+bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, const int *k_dev, int kmax, int F,
+                  float alpha, float beta, float *C, long ldc, hipStream_t s);
+// C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
+// the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
+bool skinny_product_f32(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
+                        long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s);
 size_t gemm_slab_floats(int M, int N, int split_k);
 
 // ---------------------------------------------------------------------------
@@ -165,6 +174,10 @@ void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, fl
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
                  hipStream_t s);
 size_t jacobi_work_floats(int n);
+// CholQR building blocks for panels of <= 64 rows: Cholesky of the panel's Gram matrix with
+// dead-row detection, and the forward substitution Q = L^-1 Z (in place allowed).
+void chol_factor64(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl, int *dead, hipStream_t s);
+void trsm_rows64(const float *L, long ldl, const int *dead, int m, const float *Z, float *Q, long ld, int F, hipStream_t s);
 // row norms of (Y - theta_i X) and of X
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);

@@ -28,6 +28,7 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     srcrow_.alloc(cap_ + 8);
     jwork_.alloc(jacobi_work_floats(cap_));
     ibuf_.alloc(8);
+    dead_.alloc(64);
     pv_.alloc(F_);
     pw_.alloc(F_);
     slab_floats_ = std::max((size_t)4 * cap_ * F_, (size_t)8 << 20);
@@ -91,6 +92,13 @@ void EigTracker::append_random(float *Q, int have, int add)
 void EigTracker::product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
                          const float *E2, float b2)
 {
+    st_.product_rows += rows;
+    if (rows <= 128 && F_ >= 256) {
+        if (prof_) prof_->begin(PROF_EIG_PRODUCT);
+        skinny_product_f32(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, s_);
+        if (prof_) prof_->end(PROF_EIG_PRODUCT);
+        return;
+    }
     GemmArgs g;
     g.M = rows; g.N = F_; g.K = F_;
     g.A.p = X; g.A.ld = F_; g.A.kmajor = false;
@@ -106,7 +114,6 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     if (prof_) prof_->begin(PROF_EIG_PRODUCT);
     gemm_f32(g, s_);
     if (prof_) prof_->end(PROF_EIG_PRODUCT);
-    st_.product_rows += rows;
 }
 
 // T[rows][rows] (ld cap_) = X * Y^T
@@ -195,37 +202,54 @@ void EigTracker::project_out(float *Wp, int np, const float *Q, int kept)
 // range that a one-shot fp32 Gram matrix could not resolve.
 int EigTracker::orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends)
 {
+    (void)out;   // in place: no row is ever dropped here (dependent rows become zero rows)
     row_normalize(Z, F_, rows, F_, s_);
-    int kept = 0;
     // panel_ends: ascending row indices, last == rows.  Panels never mix rows of different
     // provenance or of very different filter amplification (the caller decides the cuts).
+    // Per panel: project against the rows above (twice), renormalise, CholQR2 (Gram -> Cholesky
+    // -> forward substitution, twice).  Nothing here synchronises with the host.
     size_t pi = 0;
     for (int p0 = 0; p0 < rows;) {
         while (pi < panel_ends.size() && panel_ends[pi] <= p0) pi++;
-        const int pend = pi < panel_ends.size() ? std::min(rows, panel_ends[pi]) : rows;
+        int pend = pi < panel_ends.size() ? std::min(rows, panel_ends[pi]) : rows;
+        if (pend - p0 > 64) pend = p0 + 64;
         const int np = pend - p0;
         float *Wp = Z + (size_t)p0 * F_;
-        if (kept > 0) {
+        if (p0 > 0) {
             for (int pass = 0; pass < 2; pass++) {
-                project_out(Wp, np, out, kept);
-                // after the first projection, rows that lie (to fp32 accuracy) inside the accepted span are zeroed
+                project_out(Wp, np, Z, p0);
+                // after the first projection, rows that lie (to fp32 accuracy) inside the span above are zeroed
                 row_normalize(Wp, F_, np, F_, s_, pass == 0 ? 2e-5f : 0.f);
             }
         }
-        float *dst = out + (size_t)kept * F_;
-        bool ok = false;
-        int k = whiten(Wp, np, dst, &ok);
-        if (!ok && k > 0) {
-            const int k2 = whiten(dst, k, Wp, nullptr);
-            DLCO_HIP(hipMemcpyAsync(dst, Wp, (size_t)k2 * F_ * sizeof(float), hipMemcpyDeviceToDevice, s_));
-            k = k2;
+        for (int pass = 0; pass < 2; pass++) {
+            gram(Wp, Wp, np, Tm_.p);
+            chol_factor64(Tm_.p, cap_, np, 1e-5f, Vm_.p, cap_, dead_.p, s_);
+            trsm_rows64(Vm_.p, cap_, dead_.p, np, Wp, Wp, F_, F_, s_);
         }
-        kept += k;
         p0 = pend;
-        if (kept >= F_) { kept = F_; break; }
     }
-    DLCO_CHECK(kept >= 1, -5, "eig tracker: basis collapsed during orthonormalisation");
-    return kept;
+    return rows;
+}
+
+// Remove rows that the orthonormalisation zeroed (they surface as exact-zero Ritz pairs).
+int EigTracker::drop_dead_rows()
+{
+    std::vector<int32_t> live;
+    for (int i = 0; i < m_; i++)
+        if (!(h_theta_[i] == 0.f && h_res_[i] == 0.f)) live.push_back(i);
+    const int k = (int)live.size();
+    if (k == m_ || k == 0) return m_;
+    DLCO_HIP(hipMemcpyAsync(srcrow_.p, live.data(), (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, s_));
+    DLCO_HIP(hipStreamSynchronize(s_));
+    float *Qn = pick({Q_, Y_});
+    scale_rows(Qn, F_, Q_, F_, nullptr, srcrow_.p, k, F_, s_);
+    float *Yn = pick({Q_, Y_, Qn});
+    scale_rows(Yn, F_, Y_, F_, nullptr, srcrow_.p, k, F_, s_);
+    Q_ = Qn; Y_ = Yn;
+    for (int j = 0; j < k; j++) { h_theta_[j] = h_theta_[live[j]]; h_res_[j] = h_res_[live[j]]; }
+    m_ = k;
+    return k;
 }
 
 // Power iteration for lambda_max(G); the lower end of H = -G is -lambda_max(G).
@@ -296,7 +320,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             const float minw = 1e-3f * (std::fabs(a) + std::fabs(mu)) + 1e-20f;
             if (b < a + minw) b = a + minw;
             const float c0 = 0.5f * (a + b), e0 = 0.5f * (b - a);
-            int d = it == 0 ? 4 : (it == 1 ? 6 : (it < 4 ? 8 : 10));
+            int d = std::min(12, deg0_ + 2 * it);
             const float xmax = std::max(1.5f, (std::max(theta_top, mu) - c0) / e0);
             // keep the top/guard amplification ratio T_d(xmax) below ~1e5: the guard rows survive the
             // cancellation against the amplified rows with ~1e5 * 6e-8 relative noise
@@ -318,15 +342,15 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                 const double x = std::max(1.0, (double)(h_theta_[j] - c0) / e0);
                 const double amp = std::cosh((double)d * std::acosh(x));
                 if (j == start) amp0 = amp;
-                else if (j - start >= 32 || amp0 > 30.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
+                else if (j - start >= 64 || amp0 > 30.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
             }
             if (n_ritz < m_) panel_ends.push_back(n_ritz);
         }
-        for (int j = (panel_ends.empty() ? 0 : panel_ends.back()) + 32; j < m_; j += 32) panel_ends.push_back(j);
+        for (int j = (panel_ends.empty() ? 0 : panel_ends.back()) + 64; j < m_; j += 64) panel_ends.push_back(j);
         panel_ends.push_back(m_);
         // ---- orthonormalise, Rayleigh-Ritz -------------------------------------------------------
-        float *Qo = pick({Z});
-        m_ = orthonormalize(Z, m_, Qo, panel_ends);
+        float *Qo = Z;
+        orthonormalize(Z, m_, nullptr, panel_ends);                  // in place
         float *Yb = pick({Qo});
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f);            // Yb = Qo * H
         gram(Yb, Qo, m_, Tm_.p);
@@ -347,6 +371,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         std::memcpy(h_res_.data(), pin_ + cap_, (size_t)m_ * sizeof(float));
         st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * cap_);
         have_theta_ = true;
+        drop_dead_rows();
         theta_top = h_theta_[0];
         block_min = std::min(h_theta_[m_ - 1], mu);
 
@@ -385,6 +410,10 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         if (conv) { it++; break; }
     }
     st_.iters += it;
+    // starting degree for the next step: the cheapest one that has been converging in a single
+    // filter + Rayleigh-Ritz pass (each extra pass costs a Jacobi and an orthonormalisation)
+    if (it >= 2) deg0_ = std::min(10, deg0_ + 2);
+    else if (conv && last_crit_ < 0.15f * tol_) deg0_ = std::max(2, deg0_ - 1);
     if (!conv) st_.nonconverged++;
     if (converged) *converged = conv;
 

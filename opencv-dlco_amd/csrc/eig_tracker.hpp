@@ -50,6 +50,7 @@ private:
     void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out);
     int whiten(const float *src, int k, float *dst, bool *well_conditioned);
     int orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends);   // returns kept rows
+    int drop_dead_rows();
     void refresh_lower_bound(const float *G, int iters, float theta_top);
     void append_random(float *Q, int have, int add);
     float next_uniform();
@@ -65,6 +66,7 @@ private:
     int steps_since_lo_ = 0;
     uint64_t rng_ = 0x243F6A8885A308D3ULL;
     float last_crit_ = 0.f;
+    int deg0_ = 4;                   // filter degree of the first pass of a step (adapted)
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
 
     DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F
@@ -73,6 +75,7 @@ private:
     DevBuf<float> Tm_, Vm_, Cw_, evals_, res_, jwork_, slab_, pv_, pw_, scale_;
     DevBuf<int32_t> srcrow_;
     DevBuf<int> ibuf_;               // [0] kept count, [1] sweeps
+    DevBuf<int> dead_;               // dead-row flags of the panel being factored
     size_t slab_floats_ = 0;
     std::vector<float> h_theta_, h_res_, h_tmp_, h_sc_;
     std::vector<int32_t> h_sr_;

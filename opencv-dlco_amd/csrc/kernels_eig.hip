@@ -21,134 +21,25 @@ __device__ __forceinline__ float wsum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// sum over a 16-lane DPP row, result in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);    // row_half_mirror
+    v += dpp_f<0x140>(v);    // row_mirror
+    return v;
+}
 __device__ __forceinline__ float wmax(float v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
-}
-
-// G, V: column-major n x n (column j at [j*n, j*n+n)).
-__device__ void jacobi_body(float *G, float *V, const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
-                            float *scratch /* >= 4n floats, global */, int *sweeps_out, float *red /* LDS, JW+4 */)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // ---- shift: sigma = 1.01 * max_i sum_j |T_ij| + tiny  (Gershgorin) ------------------------
-    float rmax = 0.f;
-    for (int i = wave; i < n; i += JW) {
-        float s = 0.f;
-        for (int j = lane; j < n; j += 64) s += fabsf(T[(long)i * ldt + j]);
-        s = wsum(s);
-        rmax = fmaxf(rmax, s);
-    }
-    if (lane == 0) red[wave] = rmax;
-    __syncthreads();
-    float sigma = 0.f;
-    for (int w = 0; w < JW; w++) sigma = fmaxf(sigma, red[w]);
-    sigma = 1.01f * sigma + 1e-30f;
-    __syncthreads();
-
-    // ---- init: G = T + sigma I (column j = row j by symmetry; symmetrised on the fly), V = I ----
-    for (int e = tid; e < n * n; e += JT) {
-        const int j = e / n, i = e % n;
-        const float t = 0.5f * (T[(long)i * ldt + j] + T[(long)j * ldt + i]);
-        G[e] = t + (i == j ? sigma : 0.f);
-        V[e] = (i == j) ? 1.f : 0.f;
-    }
-    __syncthreads();
-
-    const int ne = n + (n & 1);           // even player count; index n (if present) is a bye
-    const int half = ne / 2;
-    const float tol = 3e-6f;
-    int sweep = 0;
-    for (; sweep < 40; sweep++) {
-        float off_max = 0.f;
-        for (int r = 0; r < ne - 1; r++) {
-            for (int k = wave; k < half; k += JW) {
-                int p, q;
-                if (k == 0) { p = ne - 1; q = r; }
-                else { p = (r + k) % (ne - 1); q = (r - k + (ne - 1)) % (ne - 1); }
-                if (p >= n || q >= n) continue;
-                if (p > q) { const int t = p; p = q; q = t; }
-                float *gp = G + (long)p * n, *gq = G + (long)q * n;
-                float a = 0.f, b = 0.f, c = 0.f;
-                for (int i = lane; i < n; i += 64) {
-                    const float x = gp[i], y = gq[i];
-                    a += x * x; b += y * y; c += x * y;
-                }
-                a = wsum(a); b = wsum(b); c = wsum(c);
-                const float denom = sqrtf(a * b);
-                const float off = denom > 0.f ? fabsf(c) / denom : 0.f;
-                off_max = fmaxf(off_max, off);
-                if (off > tol) {
-                    const float zeta = (b - a) / (2.f * c);
-                    const float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-                    const float cs = 1.f / sqrtf(1.f + t * t), sn = cs * t;
-                    float *vp = V + (long)p * n, *vq = V + (long)q * n;
-                    for (int i = lane; i < n; i += 64) {
-                        const float x = gp[i], y = gq[i];
-                        gp[i] = cs * x - sn * y;
-                        gq[i] = sn * x + cs * y;
-                        const float u = vp[i], w = vq[i];
-                        vp[i] = cs * u - sn * w;
-                        vq[i] = sn * u + cs * w;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (lane == 0) red[wave] = off_max;
-        __syncthreads();
-        float m = 0.f;
-        for (int w = 0; w < JW; w++) m = fmaxf(m, red[w]);
-        __syncthreads();
-        if (m <= tol) { sweep++; break; }
-    }
-    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
-
-    // ---- eigenvalues: lambda_j = v_j . g_j - sigma  (g_j = (T + sigma I) v_j) --------------------
-    float *lam = scratch;                 // [n]
-    int *rank = reinterpret_cast<int *>(scratch + n);
-    for (int j = wave; j < n; j += JW) {
-        float d = 0.f, vv = 0.f;
-        for (int i = lane; i < n; i += 64) { d += V[(long)j * n + i] * G[(long)j * n + i]; vv += V[(long)j * n + i] * V[(long)j * n + i]; }
-        d = wsum(d); vv = wsum(vv);
-        if (lane == 0) lam[j] = d / vv - sigma;
-    }
-    __syncthreads();
-    // ---- sort descending (rank by counting; ties by index) and write out ---------------------------
-    for (int j = tid; j < n; j += JT) {
-        const float me = lam[j];
-        int rk = 0;
-        for (int k = 0; k < n; k++) {
-            const float o = lam[k];
-            rk += (o > me || (o == me && k < j)) ? 1 : 0;
-        }
-        rank[j] = rk;
-        evals[rk] = me;
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += JT) {
-        const int j = e / n, i = e % n;
-        Vout[(long)i * ldv + rank[j]] = V[e];
-    }
-}
-
-__global__ __launch_bounds__(JT) void jacobi_lds_kernel(const float *T, long ldt, int n, float *evals, float *Vout,
-                                                        long ldv, float *scratch, int *sweeps_out)
-{
-    extern __shared__ __attribute__((aligned(16))) float sh[];
-    float *G = sh, *V = sh + n * n, *red = sh + 2 * n * n;
-    jacobi_body(G, V, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red);
-}
-
-__global__ __launch_bounds__(JT) void jacobi_gmem_kernel(const float *T, long ldt, int n, float *evals, float *Vout,
-                                                         long ldv, float *work, int *sweeps_out)
-{
-    __shared__ float red[JW + 4];
-    float *G = work, *V = work + (long)n * n, *scratch = work + 2L * n * n;
-    jacobi_body(G, V, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red);
 }
 
 __global__ __launch_bounds__(256) void residual_kernel(const float *X, const float *Y, long ld, const float *theta,
@@ -216,28 +107,74 @@ __global__ __launch_bounds__(256) void whitener_kernel(const float *evals, const
     }
 }
 
+// Left-looking Cholesky of a Gram matrix M (n <= 64) on one wave: lane i owns row i.
+// A row whose pivot drops below rel_thresh * M_jj lies (to fp32 accuracy) in the span of the
+// rows before it: it is marked dead (L_jj = 1, rest of the column 0) and later zeroed.
+__global__ __launch_bounds__(64) void chol64_kernel(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl,
+                                                   int *dead)
+{
+    __shared__ float Ls[64][65];
+    const int i = threadIdx.x;
+    for (int j = 0; j < n; j++) {
+        float s = 0.f;
+        if (i >= j && i < n) {
+            s = 0.5f * (M[(long)i * ldm + j] + M[(long)j * ldm + i]);
+            for (int k = 0; k < j; k++) s -= Ls[i][k] * Ls[j][k];
+        }
+        const float d = __shfl(s, j, 64);
+        const float mjj = M[(long)j * ldm + j];
+        const bool is_dead = !(d > rel_thresh * mjj) || !(mjj > 0.f);
+        if (i >= j && i < n) {
+            float v;
+            if (is_dead) v = (i == j) ? 1.f : 0.f;
+            else v = (i == j) ? sqrtf(d) : s * rsqrtf(d);
+            Ls[i][j] = v;
+        }
+        if (i == j) dead[j] = is_dead ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < n)
+        for (int k = 0; k <= i; k++) L[(long)i * ldl + k] = Ls[i][k];
+}
+
+// Q = L^-1 Z for a panel of m <= 64 rows (forward substitution); thread f owns column f, so the
+// whole solve is independent per column and coalesced.  Dead rows become zero.  In place is fine.
+__global__ __launch_bounds__(256) void trsm64_kernel(const float *L, long ldl, const int *dead, int m, const float *Z,
+                                                    float *Q, long ld, int F)
+{
+    __shared__ float Ls[64][65];
+    __shared__ float qs[64][256];
+    __shared__ int dd[64];
+    for (int e = threadIdx.x; e < m * m; e += 256) { const int r = e / m, c = e % m; Ls[r][c] = (c <= r) ? L[(long)r * ldl + c] : 0.f; }
+    for (int e = threadIdx.x; e < m; e += 256) dd[e] = dead[e];
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    for (int i = 0; i < m; i++) {
+        float acc = Z[(long)i * ld + f];
+        for (int j = 0; j < i; j++) acc -= Ls[i][j] * qs[j][threadIdx.x];
+        const float q = dd[i] ? 0.f : acc / Ls[i][i];
+        qs[i][threadIdx.x] = q;
+        Q[(long)i * ld + f] = q;
+    }
+}
+
 }  // namespace
 
-size_t jacobi_work_floats(int n) { return 2 * (size_t)n * n + 4 * (size_t)n + 64; }
-
-void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                 hipStream_t s)
+void chol_factor64(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl, int *dead, hipStream_t s)
 {
-    DLCO_CHECK(n >= 1 && n <= 2048, -2, "jacobi_eigh: n out of range");
-    if (n <= JACOBI_LDS_MAX_N) {
-        const size_t lds = (2 * (size_t)n * n + JW + 4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(JT), lds, s, T, ldt, n, evals, V, ldv, work, sweeps_out);
-    } else {
-        hipLaunchKernelGGL(jacobi_gmem_kernel, dim3(1), dim3(JT), 0, s, T, ldt, n, evals, V, ldv, work, sweeps_out);
-    }
+    DLCO_CHECK(n >= 1 && n <= 64, -2, "chol_factor64: n out of range");
+    hipLaunchKernelGGL(chol64_kernel, dim3(1), dim3(64), 0, s, M, ldm, n, rel_thresh, L, ldl, dead);
     DLCO_HIP(hipGetLastError());
 }
+
+void trsm_rows64(const float *L, long ldl, const int *dead, int m, const float *Z, float *Q, long ld, int F, hipStream_t s)
+{
+    DLCO_CHECK(m >= 1 && m <= 64, -2, "trsm_rows64: m out of range");
+    hipLaunchKernelGGL(trsm64_kernel, dim3((F + 255) / 256), dim3(256), 0, s, L, ldl, dead, m, Z, Q, ld, F);
+    DLCO_HIP(hipGetLastError());
+}
+
 
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s)

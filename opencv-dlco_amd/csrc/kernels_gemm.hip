@@ -215,6 +215,155 @@ __global__ void splitk_reduce_kernel(const float *slab, int split, int M, int N,
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// Skinny product of the eigen tracker: out[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2
+// with M <= 128 (MT = ceil(M/32) row tiles), G row-major.  One workgroup owns 32 output
+// columns for ALL rows; its four waves split K four ways and never synchronise inside the
+// K loop (each wave stages its own X tile through a private LDS region, G fragments go
+// straight from global memory to registers: 32 lanes read one 128-byte row segment).
+// The four partial accumulators are summed through LDS in wave order at the end, so the
+// result is deterministic and no split-K slab or second launch is needed.
+// -----------------------------------------------------------------------------------------
+struct SkinnyDev {
+    int M, N, K;
+    const float *X;
+    long ldx;
+    const float *G;
+    long ldg;
+    float *C;
+    long ldc;
+    float alpha, b1, b2;
+    const float *E1, *E2;
+    int xvec_ok;
+};
+
+constexpr int SKW = 8;                           // waves per skinny workgroup (K split 8 ways)
+constexpr int SKT = 64 * SKW;
+
+template <int MT>
+__global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyDev g)
+{
+    constexpr int MP = 32 * MT;                  // padded rows
+    constexpr int LDA = MP + PAD;
+    __shared__ __attribute__((aligned(16))) float As[SKW][2][BK][LDA];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int col = n0 + lc;
+    const bool col_ok = col < g.N;
+
+    // K range of this wave (multiple of BK)
+    int kq = ((g.K + SKW - 1) / SKW + BK - 1) / BK * BK;
+    const int kbeg = wave * kq;
+    const int kend = min(g.K, kbeg + kq);
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+
+    // X tile loader: lane -> (row = lane/4 + 16u, k-quad = lane%4), float4 along k
+    constexpr int AU = MP / 16;
+    f32x4 ra[AU];
+    float rb0[BK / 2], rb1[BK / 2];              // G fragments of the next two K tiles (HBM latency cover)
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const int row = (lane >> 2) + 16 * u, k = k0 + (lane & 3) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < g.M && k < kend) {
+                const float *src = g.X + (long)row * g.ldx + k;
+                if (g.xvec_ok && k + 3 < kend) v = *reinterpret_cast<const f32x4 *>(src);
+                else {
+                    v[0] = src[0];
+                    if (k + 1 < kend) v[1] = src[1];
+                    if (k + 2 < kend) v[2] = src[2];
+                    if (k + 3 < kend) v[3] = src[3];
+                }
+            }
+            ra[u] = v;
+        }
+    };
+    auto load_b = [&](int k0, float (&rb)[BK / 2]) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            const int k = k0 + 2 * kk + lh;
+            rb[kk] = (col_ok && k < kend) ? g.G[(long)k * g.ldg + col] : 0.f;
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < AU; u++) {
+            const int row = (lane >> 2) + 16 * u, kq4 = (lane & 3) * 4;
+            As[wave][buf][kq4 + 0][row] = ra[u][0];
+            As[wave][buf][kq4 + 1][row] = ra[u][1];
+            As[wave][buf][kq4 + 2][row] = ra[u][2];
+            As[wave][buf][kq4 + 3][row] = ra[u][3];
+        }
+    };
+
+    if (nk > 0) {
+        load_a(kbeg);
+        load_b(kbeg, rb0);
+        load_b(kbeg + BK, rb1);
+        store_a(0);
+    }
+    // one K tile: consume the fragments in `bcur`, refill them for tile kt+2, stage X tile kt+1
+    auto tile = [&](int kt, float (&bcur)[BK / 2]) {
+        const int buf = kt & 1;
+        float bf[BK / 2];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) bf[kk] = bcur[kk];
+        if (kt + 1 < nk) load_a(kbeg + (kt + 1) * BK);
+        if (kt + 2 < nk) load_b(kbeg + (kt + 2) * BK, bcur);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+#pragma unroll
+            for (int a = 0; a < MT; a++) {
+                const float af = As[wave][buf][2 * kk + lh][a * 32 + lc];
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[kk], acc[a], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_a(buf ^ 1);       // private region: ordered by this wave's own LDS counter
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile(kt, rb0);
+        if (kt + 1 < nk) tile(kt + 1, rb1);
+    }
+
+    // ---- combine the K-partials in wave order through LDS (reusing the staging space) ----------
+    __syncthreads();
+    float *red = &As[0][0][0][0];
+    static_assert((SKW - 1) * MT * 16 * 64 <= SKW * 2 * BK * LDA, "reduction scratch does not fit");
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[(((wave - 1) * MT + a) * 16 + r) * 64 + lane] = acc[a][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float s = acc[a][r];
+#pragma unroll
+                for (int w = 0; w < SKW - 1; w++) s += red[((w * MT + a) * 16 + r) * 64 + lane];
+                const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < g.M && col_ok) {
+                    const long idx = (long)i * g.ldc + col;
+                    float o = g.alpha * s;
+                    if (g.E1) o += g.b1 * g.E1[idx];
+                    if (g.E2) o += g.b2 * g.E2[idx];
+                    g.C[idx] = o;
+                }
+            }
+    }
+}
+
 template <int WM, int WN>
 void launch(const GemmDev &g, bool akm, bool bkm, dim3 grid, hipStream_t s)
 {
@@ -229,6 +378,25 @@ inline int vec_ok(const GemmOperand &o) { return (o.ld % 4 == 0) && ((reinterpre
 }  // namespace
 
 size_t gemm_slab_floats(int M, int N, int split_k) { return split_k > 1 ? (size_t)split_k * M * N : 0; }
+
+bool skinny_product_f32(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
+                        long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s)
+{
+    if (M < 1 || M > 128 || N < 1) return false;
+    SkinnyDev g;
+    g.M = M; g.N = N; g.K = K;
+    g.X = X; g.ldx = ldx; g.G = G; g.ldg = ldg; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.E1 = E1; g.b1 = b1; g.E2 = E2; g.b2 = b2;
+    g.xvec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const dim3 grid((N + 31) / 32), block(SKT);
+    const int mt = (M + 31) / 32;
+    if (mt == 1) hipLaunchKernelGGL(skinny_kernel<1>, grid, block, 0, s, g);
+    else if (mt == 2) hipLaunchKernelGGL(skinny_kernel<2>, grid, block, 0, s, g);
+    else if (mt == 3) hipLaunchKernelGGL(skinny_kernel<3>, grid, block, 0, s, g);
+    else hipLaunchKernelGGL(skinny_kernel<4>, grid, block, 0, s, g);
+    DLCO_HIP(hipGetLastError());
+    return true;
+}
 
 void gemm_f32(const GemmArgs &a, hipStream_t s)
 {

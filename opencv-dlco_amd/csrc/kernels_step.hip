@@ -58,14 +58,41 @@ __global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rh
 __global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
                                    const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int k = 0;
-    for (int i = lo; i < hi && i < B; i++)
-        if (rho[i] != 0) { ids[k] = pos_rows[i]; w[k] = (float)rho[i]; k++; }
-    for (int j = lo; j < hi && j < B; j++)
-        if (kappa[j] != 0) { ids[k] = neg_rows[j]; w[k] = -(float)kappa[j]; k++; }
-    *k_active = k;
-    for (int z = k; z < 2 * B; z++) { ids[z] = 0; w[z] = 0.f; }
+    // ordered stream compaction of the 2*(hi-lo) candidates (positives first) by one workgroup:
+    // chunk-wise ballot + prefix over the waves keeps the output order equal to the slot order
+    __shared__ int wave_cnt[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int n_own = max(0, min(hi, B) - lo), total = 2 * n_own;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < total; c0 += blockDim.x) {
+        const int e = c0 + tid;
+        int id = 0;
+        float wt = 0.f;
+        bool keep = false;
+        if (e < total) {
+            if (e < n_own) { const int i = lo + e; keep = rho[i] != 0; id = pos_rows[i]; wt = (float)rho[i]; }
+            else { const int j = lo + e - n_own; keep = kappa[j] != 0; id = neg_rows[j]; wt = -(float)kappa[j]; }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int v = 0; v < wave; v++) off += wave_cnt[v];
+        if (keep) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            ids[pos] = id;
+            w[pos] = wt;
+        }
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int v = 0; v < nw; v++) s += wave_cnt[v]; base += s; }
+        __syncthreads();
+    }
+    const int k = base;
+    if (tid == 0) *k_active = k;
+    // zero padding up to the next multiple of 32 entries: the SYRK consumes whole K tiles
+    for (int z = k + tid; z < ((2 * B + 31) & ~31); z += blockDim.x) { ids[z] = 0; w[z] = 0.f; }
 }
 
 // H1 (src/kernelop-opencv.cu:49-66): one thread per positive row, the inner sum runs over the
@@ -198,7 +225,7 @@ void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t 
 void build_active_rows(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho, const int32_t *kappa,
                        int B, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(64), 0, s, pos_rows, neg_rows, rho, kappa, B, slot_lo, slot_hi,
+    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(256), 0, s, pos_rows, neg_rows, rho, kappa, B, slot_lo, slot_hi,
                        ids, w, k_active);
     DLCO_HIP(hipGetLastError());
 }

@@ -1,0 +1,196 @@
+// kernels_syrk.hip — the dominant kernel of the pj-learn step on gfx950:
+//
+//     dfAvg  <-  beta * dfAvg  +  alpha * sum_k  w_k * x_k x_k^T          (Q1 + U1)
+//
+// x_k = row ids[k] of the resident PR-descriptor-difference matrix D [N,F], w_k = rho_i for
+// a positive row, -kappa_j for a negative one (src/pj-learn.cpp:367-422 in the reformulated
+// order P^T diag(rho) P - N^T diag(kappa) N; rows with zero weight are not in the list).
+//
+// Design (MI355X): the output is symmetric, so only the 128x128 tiles on or above the
+// diagonal are computed (nt(nt+1)/2 workgroups, dealt to the 8 XCDs in contiguous chunks so
+// that neighbouring tiles share their row panels in one L2) and each tile is also stored
+// transposed.  Both MFMA operands are k-major images of gathered rows (lane l reads element
+// l&31 of row 2kk + (l>>5): conflict-free ds_read_b32), staged through registers with the
+// row ids one tile ahead of the data so that the gather's two dependent loads never sit in
+// the same iteration.  The hot loop is branch-free; the row list is zero-padded to the tile
+// depth by the kernel that builds it.  Epilogue: dual-average update in registers, direct
+// store of the tile, transposed store through LDS as whole 512-byte rows.  Exact fp32
+// (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain).
+#include "dlco_internal.hpp"
+
+namespace dlco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TB = 128;           // tile edge
+constexpr int KB = 32;            // K depth per LDS stage
+constexpr int LD = TB + 4;        // LDS row pitch of the k-major images
+constexpr int TLD = TB + 1;       // pitch of the transpose buffer
+constexpr int NTH = 256;
+
+struct SyrkDev {
+    const float *D;
+    long ldd;
+    const int32_t *ids;
+    const float *w;
+    const int *k_dev;             // device-resident active row count
+    int kmax;                     // capacity of ids/w (multiple of KB, zero padded)
+    int F;
+    float *C;
+    long ldc;
+    float alpha, beta;
+    int nt;                       // tiles per edge
+};
+
+union SyrkLds {
+    struct { float A[2][KB][LD]; float B[2][KB][LD]; } st;    // 67,584 B
+    float T[TB][TLD];                                          // 66,048 B
+};
+
+__global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
+{
+    __shared__ __attribute__((aligned(16))) SyrkLds lds;
+
+    // ---- tile assignment: XCD-contiguous chunks over the upper-triangular tile list ---------
+    const int ntiles = g.nt * (g.nt + 1) / 2;
+    const int nxcd = 8;
+    const int bid = blockIdx.x;
+    int t;
+    {
+        const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;     // bijective remap
+    }
+    // row-major enumeration of (bi <= bj): tile t -> (bi, bj)
+    int bi = 0, rem = t;
+    {
+        // solve bi: offset(bi) = bi*nt - bi*(bi-1)/2 <= t
+        float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
+        bi = max(0, min(g.nt - 1, (int)fb));
+        while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
+        while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
+        rem = t - (bi * g.nt - bi * (bi - 1) / 2);
+    }
+    const int bj = bi + rem;
+    const int i0 = bi * TB, j0 = bj * TB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    const int kact = min(*g.k_dev, g.kmax);
+    const int nk = (kact + KB - 1) / KB;          // the list is zero padded up to a multiple of KB
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    // loader mapping: 4 float4 per operand per thread; f = tid + 256u -> row = f / 32, c4 = f % 32
+    const int c4 = tid & 31, rbase = tid >> 5;    // rows rbase, rbase + 8, rbase + 16, rbase + 24
+    int32_t id_nx[4];
+    float w_nx[4];
+    f32x4 ra[4], rb[4];
+
+    auto load_ids = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = kt * KB + rbase + 8 * u;
+            id_nx[u] = g.ids[k];
+            w_nx[u] = g.w[k];
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float *row = g.D + (long)id_nx[u] * g.ldd;
+            f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
+            f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
+            ra[u] = xa * w_nx[u];
+            rb[u] = xb;
+        }
+    };
+    auto store_rows = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            *reinterpret_cast<f32x4 *>(&lds.st.A[buf][rbase + 8 * u][c4 * 4]) = ra[u];
+            *reinterpret_cast<f32x4 *>(&lds.st.B[buf][rbase + 8 * u][c4 * 4]) = rb[u];
+        }
+    };
+
+    if (nk > 0) {
+        load_ids(0);
+        load_rows();
+        if (nk > 1) load_ids(1);
+        store_rows(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_rows();                         // data of tile kt+1 (ids already here)
+        if (kt + 2 < nk) load_ids(kt + 2);                    // ids of tile kt+2
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < KB / 2; kk++) {
+            const float a0 = lds.st.A[buf][2 * kk + lk][wm * 64 + lr];
+            const float a1 = lds.st.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
+            const float b0 = lds.st.B[buf][2 * kk + lk][wn * 64 + lr];
+            const float b1 = lds.st.B[buf][2 * kk + lk][wn * 64 + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 1 < nk) store_rows(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: out = beta*old + alpha*acc on the upper tile; mirror below the diagonal -------
+    const bool diag = (bi == bj);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int jl = wn * 64 + b * 32 + lr;
+                const long idx = (long)(i0 + il) * g.ldc + (j0 + jl);
+                float o = 0.f;
+                if (!diag || jl >= il) {
+                    o = g.alpha * acc[a][b][r];
+                    if (g.beta != 0.f) o += g.beta * g.C[idx];
+                    g.C[idx] = o;
+                }
+                lds.T[il][jl] = o;
+            }
+    __syncthreads();
+    // transposed store: output row (j0 + jl), columns i0 + il; a wave writes whole 512-byte rows
+    for (int e = tid; e < TB * TB; e += NTH) {
+        const int jl = e / TB, il = e % TB;
+        if (diag ? (jl > il) : true) g.C[(long)(j0 + jl) * g.ldc + (i0 + il)] = lds.T[il][jl];
+    }
+}
+
+}  // namespace
+
+bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, const int *k_dev, int kmax, int F,
+                  float alpha, float beta, float *C, long ldc, hipStream_t s)
+{
+    if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
+    SyrkDev g;
+    g.D = D; g.ldd = ldd; g.ids = ids; g.w = w; g.k_dev = k_dev; g.kmax = kmax; g.F = F;
+    g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
+    const int ntiles = g.nt * (g.nt + 1) / 2;
+    hipLaunchKernelGGL(syrk_rda_kernel, dim3(ntiles), dim3(NTH), 0, s, g);
+    DLCO_HIP(hipGetLastError());
+    return true;
+}
+
+}  // namespace dlco

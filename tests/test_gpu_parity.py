@@ -134,6 +134,33 @@ def test_grad_rda(small, ref, B, zero_frac):
     assert np.array_equal(got, got.T)            # upper triangle mirrored: exactly symmetric
 
 
+@pytest.mark.parametrize("F,B,zero_frac", [(128, 8, 0.0), (256, 200, 0.3), (384, 33, 0.9), (256, 16, 1.0)])
+def test_grad_rda_fused_kernel(dlco, ref, F, B, zero_frac):
+    """F a multiple of 128 takes the fused symmetric SYRK + dual-average kernel (kernels_syrk.hip)."""
+    N = 1500
+    D, L = synth(N, F, k=10, seed=F + B)
+    ctx = dlco.Context(F, N, B=B)
+    ctx.set_data(D, L)
+    rng = np.random.default_rng(F * 7 + B)
+    pr = rng.integers(0, N, B).astype(np.int32)
+    nr = rng.integers(0, N, B).astype(np.int32)
+    rho = rng.integers(0, B + 1, B).astype(np.int32)
+    kap = rng.integers(0, B + 1, B).astype(np.int32)
+    rho[rng.random(B) < zero_frac] = 0
+    kap[rng.random(B) < zero_frac] = 0
+    df0 = rng.standard_normal((F, F)).astype(np.float32)
+    df0 = (df0 + df0.T) * np.float32(0.5)
+    alpha, beta = np.float32(1.0 / (B * B * 3)), np.float32(2.0 / 3.0)
+    got = ctx.grad_rda(pr, nr, rho, kap, float(alpha), float(beta), df0)
+    want = np.float64(beta) * df0 + np.float64(alpha) * ref.grad_reform(D[pr], D[nr], rho, kap, f64=True)
+    assert relmax(got, want) <= TOL_GRAD
+    assert np.array_equal(got, got.T)
+    # beta = 0 must not read the (possibly uninitialised) previous contents
+    got0 = ctx.grad_rda(pr, nr, rho, kap, 1.0, 0.0, None)
+    assert relmax(got0, ref.grad_reform(D[pr], D[nr], rho, kap, f64=True)) <= TOL_GRAD
+    ctx.close()
+
+
 def test_hinge_sum(small, ref):
     ctx = small[0]
     rng = np.random.default_rng(11)
