@@ -137,8 +137,8 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, 
                   float alpha, float beta, float *C, long ldc, hipStream_t s);
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
-bool skinny_product_f32(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
-                        long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s);
+bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,
+                        float alpha, float *C, long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s);
 size_t gemm_slab_floats(int M, int N, int split_k);
 
 // ---------------------------------------------------------------------------

@@ -95,7 +95,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     st_.product_rows += rows;
     if (rows <= 128 && F_ >= 256) {
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
-        skinny_product_f32(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, s_);
+        skinny_product_f32(X, F_, rows, cap_, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, s_);
         if (prof_) prof_->end(PROF_EIG_PRODUCT);
         return;
     }

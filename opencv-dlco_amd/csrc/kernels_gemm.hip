@@ -240,7 +240,9 @@ struct SkinnyDev {
 constexpr int SKW = 8;                           // waves per skinny workgroup (K split 8 ways)
 constexpr int SKT = 64 * SKW;
 
-template <int MT>
+// FAST: N % 32 == 0, K % (SKW*BK) == 0, X 16-byte aligned with at least 32*MT allocated rows:
+// no bounds checks anywhere in the K loop (rows beyond M are computed and discarded).
+template <int MT, bool FAST>
 __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyDev g)
 {
     constexpr int MP = 32 * MT;                  // padded rows
@@ -272,6 +274,10 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyDev g)
 #pragma unroll
         for (int u = 0; u < AU; u++) {
             const int row = (lane >> 2) + 16 * u, k = k0 + (lane & 3) * 4;
+            if (FAST) {
+                ra[u] = *reinterpret_cast<const f32x4 *>(g.X + (long)row * g.ldx + k);
+                continue;
+            }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < g.M && k < kend) {
                 const float *src = g.X + (long)row * g.ldx + k;
@@ -290,7 +296,8 @@ __global__ __launch_bounds__(SKT) void skinny_kernel(SkinnyDev g)
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
             const int k = k0 + 2 * kk + lh;
-            rb[kk] = (col_ok && k < kend) ? g.G[(long)k * g.ldg + col] : 0.f;
+            if (FAST) rb[kk] = g.G[(long)k * g.ldg + col];
+            else rb[kk] = (col_ok && k < kend) ? g.G[(long)k * g.ldg + col] : 0.f;
         }
     };
     auto store_a = [&](int buf) {
@@ -379,8 +386,8 @@ inline int vec_ok(const GemmOperand &o) { return (o.ld % 4 == 0) && ((reinterpre
 
 size_t gemm_slab_floats(int M, int N, int split_k) { return split_k > 1 ? (size_t)split_k * M * N : 0; }
 
-bool skinny_product_f32(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
-                        long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s)
+bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,
+                        float alpha, float *C, long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s)
 {
     if (M < 1 || M > 128 || N < 1) return false;
     SkinnyDev g;
@@ -390,10 +397,18 @@ bool skinny_product_f32(const float *X, long ldx, int M, const float *G, long ld
     g.xvec_ok = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const dim3 grid((N + 31) / 32), block(SKT);
     const int mt = (M + 31) / 32;
-    if (mt == 1) hipLaunchKernelGGL(skinny_kernel<1>, grid, block, 0, s, g);
-    else if (mt == 2) hipLaunchKernelGGL(skinny_kernel<2>, grid, block, 0, s, g);
-    else if (mt == 3) hipLaunchKernelGGL(skinny_kernel<3>, grid, block, 0, s, g);
-    else hipLaunchKernelGGL(skinny_kernel<4>, grid, block, 0, s, g);
+    const bool fast = g.xvec_ok && (N % 32 == 0) && (K % (SKW * BK) == 0) && x_rows_alloc >= 32 * mt;
+    if (fast) {
+        if (mt == 1) hipLaunchKernelGGL((skinny_kernel<1, true>), grid, block, 0, s, g);
+        else if (mt == 2) hipLaunchKernelGGL((skinny_kernel<2, true>), grid, block, 0, s, g);
+        else if (mt == 3) hipLaunchKernelGGL((skinny_kernel<3, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((skinny_kernel<4, true>), grid, block, 0, s, g);
+    } else {
+        if (mt == 1) hipLaunchKernelGGL((skinny_kernel<1, false>), grid, block, 0, s, g);
+        else if (mt == 2) hipLaunchKernelGGL((skinny_kernel<2, false>), grid, block, 0, s, g);
+        else if (mt == 3) hipLaunchKernelGGL((skinny_kernel<3, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((skinny_kernel<4, false>), grid, block, 0, s, g);
+    }
     DLCO_HIP(hipGetLastError());
     return true;
 }
