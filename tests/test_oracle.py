@@ -1,0 +1,224 @@
+"""CPU tests of the oracle (oracle/dlco_ref.c): pins against the reference's own artefacts
+(tests/golden/ref_results.npz, ref_log_head.txt — outputs the reference committed), frozen
+golden vectors, and independent numpy restatements of each formula.  No GPU needed."""
+import re
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, golden, relmax, synth
+
+
+# --------------------------------------------------------------------------- reference artefacts
+def test_pin_psd_projection_conventions_on_reference_results(ref):
+    """E2 conventions against the reference's committed result file: feeding its saved A back
+    through the oracle's eigendecomposition must reproduce its saved W (rows = sqrt(e)*v in
+    ascending eigenvalue order, up to sign) and A itself."""
+    z = golden("ref_results.npz")
+    W, A = z["r0_W"], z["r0_A"]
+    Ap, Wo, ev = ref.psd_project(A)
+    r = W.shape[0]
+    assert relmax(Ap, A) <= 1e-5
+    Wt = Wo[-r:]                                  # the r largest eigenpairs, ascending like the file
+    assert np.allclose(ev[-r:], (W.astype(np.float64) ** 2).sum(1), rtol=2e-4, atol=1e-7)
+    sgn = np.sign((Wt * W).sum(1))
+    err = np.abs(Wt * sgn[:, None] - W).max(1) / np.abs(W).max(1)
+    assert np.median(err) <= 1e-3 and err.max() <= 2e-2      # close eigenvalues rotate a little
+    # everything below the r-th eigenvalue is fp32 noise of a rank-r matrix
+    assert np.abs(ev[:-r]).max() <= 1e-5 * ev[-1]
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_pin_regulariser_and_invariants_on_reference_results(ref, k):
+    """Regul = mu * trace(A) (src/pj-learn.cpp:527) equals the value the reference logged for the
+    saved entry; W rows are orthogonal with ascending norms; Dim == Rank == rows(W)."""
+    z = golden("ref_results.npz")
+    W = z["r%d_W" % k]
+    mu, gamma, step, loss, regul, rank, dim, auc, fpr = z["r%d_info" % k]
+    assert W.shape[0] == int(rank) == int(dim)
+    tr = float(z["r%d_traceA" % k])
+    assert abs(mu * tr - regul) <= 1.5e-6                                # logged with 6 decimals
+    assert abs((W.astype(np.float64) ** 2).sum() - tr) <= 1e-5 * tr      # trace(W^T W) == trace(A)
+    G = W.astype(np.float64) @ W.T.astype(np.float64)
+    n2 = np.diag(G)
+    assert np.abs(G - np.diag(n2)).max() <= 2e-4 * n2.max()
+    assert (np.diff(n2) > 0).all()
+    if k == 0:
+        A = z["r0_A"]
+        assert relmax(W.T.astype(np.float64) @ W.astype(np.float64), A) <= 1e-6
+        assert relmax(A, A.T) <= 1e-6              # A = Evec * Bmul via sgemm: symmetric to fp32 rounding
+        assert abs(ref.lib().dlco_ref_trace(A.ctypes.data_as(ref.c_f32p), A.shape[0]) - tr) <= 1e-9
+
+
+def test_reference_log_grammar_fixture():
+    """The stdout grammar the reference's scripts scrape (workspace/08-pjlearn.sh:17, 09-pjstats.sh:28)."""
+    lines = open(GOLDEN + "/ref_log_head.txt").read().splitlines()
+    assert re.match(r"^mu: \S+ gamma: \S+ (maxdim: \d+ )?nIters: \d+$", lines[0])
+    assert lines[1].startswith("Load Labels: ") and re.match(r"^Load Distances: \d+ x \d+$", lines[2])
+    assert lines[3] == "0...10...20...30...40...50...60...70...80...90...100 - done."
+    best = [l for l in lines if l.startswith("Best: ")]
+    assert best and all(re.match(r"^Best: \d+  Loss: \d+\.\d{6} Regul: \d+\.\d{6} Obj: \d+\.\d{6} \(\d+\.\d{6}\) Rank: \d+ \(\d+\) Ttime: \d+\.\d{4} Vtime: \d+\.\d{4}$", l) for l in best)
+    stat = [l for l in lines if l.startswith("Stat: ")]
+    assert stat and all(re.match(r"^Stat: Dim \[\d+\] AUC: \d\.\d{6} \(\d\.\d{6}\) FPR95: \d+\.\d{2} \(\d+\.\d{2}\)( \[saved\])?$", l) for l in stat)
+
+
+# --------------------------------------------------------------------------- frozen oracle vectors
+def test_rng_matches_frozen_vectors_and_independent_restatement(ref):
+    z = golden("oracle_rng.npz")
+
+    def mwc(state, n):      # OpenCV's RNG::next(), restated independently in Python integers
+        out = []
+        for _ in range(n):
+            state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+            out.append(state & 0xFFFFFFFF)
+        return out
+
+    for seed in (2215, 0xFFFFFFFF):
+        r = ref.Rng(seed)
+        got = [r.next() for _ in range(64)]
+        assert got == mwc(seed, 64) == [int(v) for v in z["rng_next_%d" % seed]]
+    r = ref.Rng(2215)
+    ip, ineg = r.sample(200000, 200000, 200)
+    assert np.array_equal(ip, z["sample_200k_pos"]) and np.array_equal(ineg, z["sample_200k_neg"])
+    seq = mwc(2215, 400)
+    assert [int(v) for v in ip] == [s % 200000 for s in seq[0::2]] and [int(v) for v in ineg] == [s % 200000 for s in seq[1::2]]
+    assert np.array_equal(ref.Rng(0xFFFFFFFF).shuffle(np.arange(16, dtype=np.int32)), z["shuffle16"])
+    assert [ref.split(n) for n in (250000, 2500, 1, 0, 7, 1999)] == [int(v) for v in z["split"]] == [200000, 2000, 0, 0, 5, 1599]
+
+
+def test_index_build_properties(ref):
+    z = golden("oracle_rng.npz")
+    labels = (np.arange(500000) % 2 == 0).astype(np.uint8)
+    pos, neg = ref.build_index(labels)
+    assert np.array_equal(pos[:8], z["idx500k_pos_head"]) and np.array_equal(neg[-8:], z["idx500k_neg_tail"])
+    assert np.array_equal(np.sort(pos), np.arange(0, 500000, 2)) and np.array_equal(np.sort(neg), np.arange(1, 500000, 2))
+    # labels other than 0/1 are ignored (src/pj-learn.cpp:218-219); empty classes are fine
+    lab = np.array([1, 2, 0, 1, 7, 0, 0], np.uint8)
+    p, n = ref.build_index(lab)
+    assert sorted(p) == [0, 3] and sorted(n) == [2, 5, 6]
+    p, n = ref.build_index(np.ones(5, np.uint8))
+    assert len(n) == 0 and sorted(p) == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("fname", ["oracle_step_F32_B8.npz", "oracle_step_F64_B40.npz"])
+def test_trainer_reproduces_frozen_step_vectors(ref, fname):
+    z = golden(fname)
+    N, F, B, mu, gamma, nstep = z["cfg"]
+    tr = ref.Trainer(z["D"], z["L"], B=int(B), mu=float(mu), gamma=float(gamma), grad_order=0)
+    for s in range(int(nstep)):
+        tr.step()
+        pr, nr = tr.batch_ids()
+        assert np.array_equal(pr, z["s%d_pos_rows" % s]) and np.array_equal(nr, z["s%d_neg_rows" % s])
+        st = tr.state()
+        assert relmax(st["dfavg"], z["s%d_dfavg" % s]) <= 1e-6          # OpenBLAS threading may reorder sums
+        assert relmax(st["A"], z["s%d_A" % s]) <= 1e-4
+        assert st["r"] == z["s%d_W" % s].shape[0]
+    tr.close()
+
+
+# --------------------------------------------------------------------------- formula restatements
+def test_project_sqdist_against_numpy(ref):
+    rng = np.random.default_rng(1)
+    W = rng.standard_normal((9, 40)).astype(np.float32)
+    X = rng.standard_normal((33, 40)).astype(np.float32)
+    want = ((X.astype(np.float64) @ W.T.astype(np.float64)) ** 2).sum(1)
+    assert np.allclose(ref.project_sqdist(W, X), want, rtol=1e-5)
+    assert np.array_equal(ref.project_sqdist(W[:0], X), np.zeros(33, np.float32))
+
+
+def test_gradient_orders_agree_with_fp64(ref):
+    """Reference loop order (per-positive gather + two sgemm) == reformulated weighted SYRK."""
+    D, _ = synth(400, 48, k=8, seed=3)
+    rng = np.random.default_rng(2)
+    P, Ng = D[rng.integers(0, 400, 30)], D[rng.integers(0, 400, 30)]
+    W = (rng.standard_normal((5, 48)) * 0.4).astype(np.float32)
+    pd, nd = ref.project_sqdist(W, P), ref.project_sqdist(W, Ng)
+    rho, kap = ref.viol_counts(pd, nd)
+    assert rho.sum() == kap.sum() and 0 < rho.sum() < 900
+    g_ref = ref.grad_reforder(P, Ng, pd, nd)
+    g_new = ref.grad_reform(P, Ng, rho, kap)
+    g64 = ref.grad_reform(P, Ng, rho, kap, f64=True)
+    assert relmax(g_ref, g64) <= 3e-6 and relmax(g_new, g64) <= 3e-6
+    mask = (pd[:, None] + np.float32(1.0)) > nd[None, :]
+    assert np.array_equal(rho, mask.sum(1)) and np.array_equal(kap, mask.sum(0))
+    P64, N64 = P.astype(np.float64), Ng.astype(np.float64)
+    want = sum(mask[i].sum() * np.outer(P64[i], P64[i]) - N64[mask[i]].T @ N64[mask[i]] for i in range(30))
+    assert relmax(g64, want) <= 1e-12
+
+
+def test_rda_and_dual_to_primal(ref):
+    rng = np.random.default_rng(4)
+    F, B, t = 12, 200, 37
+    df = rng.standard_normal((F, F)).astype(np.float32)
+    dl = rng.standard_normal((F, F)).astype(np.float32)
+    got = ref.rda_update(df, dl, t, B)
+    want = df * np.float32(t / (t + 1)) + dl * (np.float32(1.0) / np.float32(B * B * (t + 1)))
+    assert np.array_equal(got, want)
+    A = ref.dual_to_primal(got, 0.003, 0.5, t)
+    Aw = (got.astype(np.float64) + 0.003 * np.eye(F)) * (-np.sqrt(t + 1.0) / 0.5)
+    Aw = 0.5 * (Aw + Aw.T)
+    assert relmax(A, Aw) <= 1e-6 and np.array_equal(A, A.T)
+
+
+def test_psd_project_against_numpy_and_zero_quirk(ref):
+    rng = np.random.default_rng(5)
+    F = 24
+    M = rng.standard_normal((F, F)).astype(np.float32)
+    M = (M + M.T) * np.float32(0.5)
+    Ap, W, ev = ref.psd_project(M)
+    w, V = np.linalg.eigh(M.astype(np.float64))
+    assert np.allclose(ev, w, atol=1e-5)
+    want = (V * np.maximum(w, 0)) @ V.T
+    assert relmax(Ap, want) <= 1e-5
+    assert W.shape[0] == int((w > 0).sum()) and relmax(W.T.astype(np.float64) @ W.astype(np.float64), want) <= 1e-5
+    # no positive eigenvalue: the reference resets W to F x F zeros (src/pj-learn.cpp:489-490)
+    Ap, W, _ = ref.psd_project(-np.eye(F, dtype=np.float32))
+    assert W.shape == (F, F) and not W.any() and not Ap.any()
+
+
+def test_hinge_sum_against_numpy(ref):
+    rng = np.random.default_rng(6)
+    p, n = (rng.random(300) * 2).astype(np.float32), (rng.random(257) * 3).astype(np.float32)
+    want = np.maximum(p.astype(np.float64)[:, None] + 1.0 - n[None, :], 0).sum()
+    assert abs(ref.hinge_sum(p, n) - want) <= 1e-5 * want
+    assert ref.hinge_sum(p, n[:0]) == 0.0
+
+
+def test_roc_stats_against_independent_restatement(ref):
+    rng = np.random.default_rng(7)
+    n = 4001
+    lab = (rng.random(n) < 0.4).astype(np.uint8)
+    lab[rng.integers(0, n, 40)] = 5
+    d = (rng.random(n) + 0.7 * (lab == 0)).astype(np.float32)
+    d[rng.integers(0, n, 300)] = np.float32(0.75)                  # ties: broken by row index
+    f95, auc = ref.roc_stats(d, lab)
+    order = np.lexsort((np.arange(n), d))
+    l = lab[order]
+    tp, fp = np.cumsum(l == 1).astype(np.float32), np.cumsum(l == 0).astype(np.float32)
+    tpr = tp * np.float32(1.0 / float(tp[-1]))
+    fpr = fp * np.float32(1.0 / float(fp[-1]))
+    assert f95 == fpr[np.argmax(tpr >= np.float32(0.95))]
+    xs = np.concatenate([fpr, [1.0]]).astype(np.float64)
+    ys = np.concatenate([tpr, [0.0]]).astype(np.float64)
+    shoelace = 0.5 * abs(np.sum(np.roll(xs, 1) * ys - np.roll(ys, 1) * xs))
+    assert abs(auc - shoelace) <= 1e-12
+    # the TPR == 0.95 edge: 19 of 20 positives ranked first
+    d2 = np.arange(40, dtype=np.float32)
+    l2 = np.array([1] * 19 + [0] * 20 + [1], np.uint8)
+    f, _ = ref.roc_stats(d2, l2)
+    assert f == np.float32(0.0)
+
+
+def test_trainer_learns_and_objective_falls(ref):
+    D, L = synth(3000, 32, k=8, seed=11, sp=0.7, noise=0.2)
+    tr = ref.Trainer(D, L, B=40, mu=0.01, gamma=0.5, grad_order=1)
+    objs = []
+    for t in range(121):
+        tr.step()
+        if t % 40 == 0:
+            lo, rg = tr.validate()
+            objs.append(lo + rg)
+    assert objs[-1] < objs[0]
+    dim, f95, auc = tr.stats()
+    assert 1 <= dim <= 32 and auc > 0.8 and 0 <= f95 <= 1
+    tr.close()
