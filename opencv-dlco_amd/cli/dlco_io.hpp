@@ -1,0 +1,218 @@
+// dlco_io.hpp — file I/O of the command-line tools.
+//
+// The reference exchanges data through HDF5 files with fixed dataset names
+// (src/pj-learn.cpp:173-212 reads "Distance" f32 [N,F] and "Label" u8 [N,1];
+// :592-597 writes "W" and "A"; src/comp-uprjdists.cpp:254-290 produces the input).
+// HDF5 is reached through dlopen of libhdf5 (no build-time dependency); a path that does not
+// end in .h5/.hdf5 is treated as a directory of .npy files with the same dataset names
+// (Distance.npy, Label.npy, W.npy, A.npy), so the tools also run where HDF5 is absent.
+#pragma once
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dlco_io {
+
+inline bool is_h5(const std::string &p)
+{
+    auto ends = [&](const char *s) { const size_t n = std::strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
+    return ends(".h5") || ends(".hdf5") || ends(".hdf");
+}
+
+// ---------------------------------------------------------------------------------- HDF5 (dlopen)
+struct H5 {
+    typedef int64_t hid_t;
+    void *h = nullptr;
+    int (*H5open)() = nullptr;
+    hid_t (*H5Fopen)(const char *, unsigned, hid_t) = nullptr;
+    hid_t (*H5Fcreate)(const char *, unsigned, hid_t, hid_t) = nullptr;
+    int (*H5Fclose)(hid_t) = nullptr;
+    hid_t (*H5Dopen2)(hid_t, const char *, hid_t) = nullptr;
+    hid_t (*H5Dcreate2)(hid_t, const char *, hid_t, hid_t, hid_t, hid_t, hid_t) = nullptr;
+    hid_t (*H5Dget_space)(hid_t) = nullptr;
+    int (*H5Sget_simple_extent_ndims)(hid_t) = nullptr;
+    int (*H5Sget_simple_extent_dims)(hid_t, unsigned long long *, unsigned long long *) = nullptr;
+    hid_t (*H5Screate_simple)(int, const unsigned long long *, const unsigned long long *) = nullptr;
+    int (*H5Dread)(hid_t, hid_t, hid_t, hid_t, hid_t, void *) = nullptr;
+    int (*H5Dwrite)(hid_t, hid_t, hid_t, hid_t, hid_t, const void *) = nullptr;
+    int (*H5Dclose)(hid_t) = nullptr;
+    int (*H5Sclose)(hid_t) = nullptr;
+    int (*H5Lexists)(hid_t, const char *, hid_t) = nullptr;
+    int (*H5Eset_auto2)(hid_t, void *, void *) = nullptr;
+    hid_t native_float = -1, native_uchar = -1;
+
+    bool load()
+    {
+        if (h) return true;
+        const char *cands[] = {getenv("DLCO_HDF5_LIB"), "libhdf5.so", "libhdf5_serial.so", "/opt/conda/lib/libhdf5.so",
+                               "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"};
+        for (const char *c : cands) {
+            if (!c || !*c) continue;
+            h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return false;
+#define DLCO_H5SYM(n) n = reinterpret_cast<decltype(n)>(dlsym(h, #n)); if (!n) return false;
+        DLCO_H5SYM(H5open) DLCO_H5SYM(H5Fopen) DLCO_H5SYM(H5Fcreate) DLCO_H5SYM(H5Fclose) DLCO_H5SYM(H5Dopen2)
+        DLCO_H5SYM(H5Dcreate2) DLCO_H5SYM(H5Dget_space) DLCO_H5SYM(H5Sget_simple_extent_ndims)
+        DLCO_H5SYM(H5Sget_simple_extent_dims) DLCO_H5SYM(H5Screate_simple) DLCO_H5SYM(H5Dread) DLCO_H5SYM(H5Dwrite)
+        DLCO_H5SYM(H5Dclose) DLCO_H5SYM(H5Sclose) DLCO_H5SYM(H5Lexists) DLCO_H5SYM(H5Eset_auto2)
+#undef DLCO_H5SYM
+        H5open();
+        H5Eset_auto2(0, nullptr, nullptr);
+        hid_t *pf = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_FLOAT_g"));
+        hid_t *pu = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_UCHAR_g"));
+        if (!pf || !pu) return false;
+        native_float = *pf; native_uchar = *pu;
+        return true;
+    }
+};
+
+inline H5 &h5()
+{
+    static H5 inst;
+    return inst;
+}
+
+// ---------------------------------------------------------------------------------- .npy (v1.0)
+inline void npy_write(const std::string &path, const void *data, const char *descr, size_t elem, const std::vector<size_t> &shape)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    std::string dict = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': (";
+    for (size_t i = 0; i < shape.size(); i++) dict += std::to_string(shape[i]) + (shape.size() == 1 || i + 1 < shape.size() ? "," : "");
+    dict += "), }";
+    while ((10 + dict.size() + 1) % 64 != 0) dict += ' ';
+    dict += '\n';
+    const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    const uint16_t hl = (uint16_t)dict.size();
+    std::fwrite(magic, 1, 8, f);
+    std::fwrite(&hl, 2, 1, f);
+    std::fwrite(dict.data(), 1, dict.size(), f);
+    size_t n = elem;
+    for (size_t s : shape) n *= s;
+    if (n && std::fwrite(data, 1, n, f) != n) { std::fclose(f); throw std::runtime_error("short write " + path); }
+    std::fclose(f);
+}
+
+inline void npy_read(const std::string &path, const char *want_descr, size_t elem, std::vector<size_t> &shape, std::vector<char> &bytes)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    unsigned char magic[10];
+    if (std::fread(magic, 1, 10, f) != 10 || std::memcmp(magic, "\x93NUMPY", 6) != 0) { std::fclose(f); throw std::runtime_error(path + ": not a .npy file"); }
+    size_t hl = magic[8] | (magic[9] << 8);
+    if (magic[6] >= 2) {                       // v2/v3: 4-byte header length
+        unsigned char more[2];
+        if (std::fread(more, 1, 2, f) != 2) { std::fclose(f); throw std::runtime_error(path + ": truncated"); }
+        hl |= ((size_t)more[0] << 16) | ((size_t)more[1] << 24);
+    }
+    std::string dict(hl, ' ');
+    if (std::fread(&dict[0], 1, hl, f) != hl) { std::fclose(f); throw std::runtime_error(path + ": truncated header"); }
+    if (dict.find(std::string("'") + want_descr + "'") == std::string::npos && dict.find(std::string("'|") + (want_descr + 1) + "'") == std::string::npos)
+        { std::fclose(f); throw std::runtime_error(path + ": expected dtype " + want_descr + ", header is " + dict); }
+    if (dict.find("'fortran_order': False") == std::string::npos) { std::fclose(f); throw std::runtime_error(path + ": fortran order not supported"); }
+    const size_t a = dict.find("'shape': ("), b = dict.find(')', a);
+    shape.clear();
+    size_t pos = a + 10;
+    while (pos < b) {
+        while (pos < b && (dict[pos] == ' ' || dict[pos] == ',')) pos++;
+        if (pos >= b) break;
+        shape.push_back(std::strtoull(dict.c_str() + pos, nullptr, 10));
+        while (pos < b && dict[pos] != ',') pos++;
+    }
+    size_t n = elem;
+    for (size_t s : shape) n *= s;
+    bytes.resize(n);
+    if (n && std::fread(bytes.data(), 1, n, f) != n) { std::fclose(f); throw std::runtime_error(path + ": truncated data"); }
+    std::fclose(f);
+}
+
+// ---------------------------------------------------------------------------------- datasets
+// Reads dataset `name` as f32 (or u8) into `out`; shape receives its dimensions.
+template <typename T>
+void read_dataset(const std::string &path, const char *name, std::vector<size_t> &shape, std::vector<T> &out)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 1, "f32 or u8 only");
+    if (is_h5(path)) {
+        H5 &L = h5();
+        if (!L.load()) throw std::runtime_error("HDF5 input requested but libhdf5 could not be loaded (set DLCO_HDF5_LIB, or pass a directory of .npy files)");
+        const H5::hid_t f = L.H5Fopen(path.c_str(), 0, 0);
+        if (f < 0) throw std::runtime_error("cannot open " + path);
+        if (L.H5Lexists(f, name, 0) <= 0) { L.H5Fclose(f); throw std::runtime_error(path + ": no dataset " + name); }
+        const H5::hid_t d = L.H5Dopen2(f, name, 0), s = L.H5Dget_space(d);
+        const int nd = L.H5Sget_simple_extent_ndims(s);
+        std::vector<unsigned long long> dims(nd > 0 ? nd : 1, 1);
+        L.H5Sget_simple_extent_dims(s, dims.data(), nullptr);
+        shape.assign(dims.begin(), dims.begin() + (nd > 0 ? nd : 0));
+        size_t n = 1;
+        for (size_t v : shape) n *= v;
+        out.resize(n);
+        const int rc = L.H5Dread(d, sizeof(T) == 4 ? L.native_float : L.native_uchar, 0, 0, 0, out.data());
+        L.H5Sclose(s); L.H5Dclose(d); L.H5Fclose(f);
+        if (rc < 0) throw std::runtime_error(path + ": read of " + name + " failed");
+    } else {
+        std::vector<char> bytes;
+        npy_read(path + "/" + name + ".npy", sizeof(T) == 4 ? "<f4" : "|u1", sizeof(T), shape, bytes);
+        out.resize(bytes.size() / sizeof(T));
+        std::memcpy(out.data(), bytes.data(), bytes.size());
+    }
+}
+
+struct Writer {
+    std::string path;
+    H5::hid_t f = -1;
+    explicit Writer(const std::string &p) : path(p)
+    {
+        if (is_h5(path)) {
+            H5 &L = h5();
+            if (!L.load()) throw std::runtime_error("HDF5 output requested but libhdf5 could not be loaded");
+            f = L.H5Fcreate(path.c_str(), 2 /* H5F_ACC_TRUNC */, 0, 0);
+            if (f < 0) throw std::runtime_error("cannot create " + path);
+        } else {
+            mkdir(path.c_str(), 0777);
+        }
+    }
+    void write_f32(const char *name, const float *data, size_t rows, size_t cols)
+    {
+        if (is_h5(path)) {
+            H5 &L = h5();
+            const unsigned long long dims[2] = {rows, cols};
+            const H5::hid_t s = L.H5Screate_simple(2, dims, nullptr);
+            const H5::hid_t d = L.H5Dcreate2(f, name, L.native_float, s, 0, 0, 0);
+            if (d < 0) throw std::runtime_error(path + ": cannot create dataset " + name);
+            if (rows != 0 && cols != 0) L.H5Dwrite(d, L.native_float, 0, 0, 0, data);
+            L.H5Dclose(d); L.H5Sclose(s);
+        } else {
+            npy_write(path + "/" + name + ".npy", data, "<f4", 4, {rows, cols});
+        }
+    }
+    ~Writer() { if (f >= 0) h5().H5Fclose(f); }
+};
+
+// GDAL-style progress bar of the reference (src/misc.cpp:45-76)
+inline int term_progress(double complete, int last_tick)
+{
+    int tick = (int)(complete * 40.0);
+    if (tick < 0) tick = 0;
+    if (tick > 40) tick = 40;
+    if (tick < last_tick && last_tick >= 39) last_tick = -1;
+    if (tick <= last_tick) return last_tick;
+    while (tick > last_tick) {
+        last_tick++;
+        if (last_tick % 4 == 0) std::printf("%d", (last_tick / 4) * 10);
+        else std::printf(".");
+    }
+    if (tick == 40) std::printf(" - done.\n");
+    else std::fflush(stdout);
+    return last_tick;
+}
+
+}  // namespace dlco_io
