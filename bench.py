@@ -8,7 +8,7 @@ A "step" is one full iteration of the reference's training loop (src/pj-learn.cp
 sample the batch, project + squared distances, violation counts, fused weighted-SYRK
 gradient + dual average, PSD projection.  Nothing is skipped inside the timed region.
 
-    python bench.py --gpus 1 --steps 40 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 300
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 Prints ONE JSON line on rank 0.
@@ -69,12 +69,12 @@ def cpu_baseline(ctx, F, B, mu, gamma, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--F", type=int, default=8192)
     ap.add_argument("--N", type=int, default=500000)
     ap.add_argument("--batch", type=int, default=200, help="pair-rows per class PER GPU")
-    ap.add_argument("--mu", type=float, default=0.01)
+    ap.add_argument("--mu", type=float, default=0.002)
     ap.add_argument("--gamma", type=float, default=0.5)
     ap.add_argument("--latent", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,6 +126,7 @@ def main():
     run(args.warmup)
     ctx.profile_enable(True)
     es0 = ctx.eig_stats()
+    cn0 = ctx.counters()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -136,6 +137,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     es1 = ctx.eig_stats()
+    cn1 = ctx.counters()
     n_syrk, ms_syrk = ctx.profile_read("grad_syrk")
     n_prod, ms_prod = ctx.profile_read("eig_product")
     n_jac, ms_jac = ctx.profile_read("jacobi")
@@ -146,7 +148,10 @@ def main():
     value = 2.0 * B * args.steps / dt
     # dominant kernel of the hot path: the fused weighted-SYRK gradient + dual average.
     # algorithmic flops per launch (dense, no symmetry credit): 2 * (2*Bl) * F^2
-    flops_launch = 4.0 * Bl * F * F
+    # only rows with a non-zero violation count enter the SYRK (the reference skips them too,
+    # src/pj-learn.cpp:378), so the per-launch figure uses the measured mean row count K <= 2*Bl.
+    k_mean = (cn1["active_rows"] - cn0["active_rows"]) / max(cn1["steps"] - cn0["steps"], 1)
+    flops_launch = 2.0 * k_mean * F * F
     ach = flops_launch / (ms_syrk / max(n_syrk, 1) * 1e-3) / 1e12 if n_syrk else None
     out = {
         "metric": "pj-learn patch-pairs/sec",
@@ -179,6 +184,9 @@ def main():
             "avg_launch_ms": ms_syrk / max(n_syrk, 1),
             "launches": n_syrk,
             "algorithmic_flops_per_launch": flops_launch,
+            "mean_active_rows_per_launch": k_mean,
+            "executed_flops_per_launch": flops_launch * (F // 128 + 1) / (2.0 * (F // 128)),
+            "tracker_nonconverged_steps": cn1["nonconverged"] - cn0["nonconverged"],
         },
         "breakdown_ms_per_step": {
             "grad_syrk": ms_syrk / args.steps,

@@ -185,6 +185,10 @@ int dlco_get_saved(dlco_ctx *ctx, float *W_host, int32_t *r, float *A_host);
  * context's stream; dlco_profile_read returns launches and their summed duration. */
 int dlco_profile_enable(dlco_ctx *ctx, int32_t on);
 int dlco_profile_read(dlco_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
+/* Counters since creation: out[0] = training steps run, out[1] = sum over those steps of the
+ * rows that entered this rank's gradient SYRK (rows with a non-zero violation count),
+ * out[2] = steps whose eigen tracker stopped at its iteration cap, out[3..7] reserved. */
+int dlco_counters(const dlco_ctx *ctx, int64_t out[8]);
 /* Tracker statistics since creation: filter/RR iterations, H-products (in rows), restarts. */
 int dlco_eig_stats(const dlco_ctx *ctx, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps,
                    int32_t *block_rows);

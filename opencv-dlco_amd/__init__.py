@@ -109,6 +109,7 @@ def load():
     L.dlco_profile_enable.argtypes = [vp, C.c_int32]
     L.dlco_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.dlco_eig_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
+    L.dlco_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -342,6 +343,11 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._ck(self.L.dlco_profile_read(self.h, kernel.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        self._ck(self.L.dlco_counters(self.h, out))
+        return dict(steps=out[0], active_rows=out[1], nonconverged=out[2])
 
     def eig_stats(self):
         a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()

@@ -49,7 +49,7 @@ struct dlco_ctx {
     int phase = 0;                   // 0 idle, 1 after begin, 2 after grad
     EigTracker *eig = nullptr;
     RocWork *roc = nullptr;
-    int64_t nonconv_steps = 0;
+    int64_t nonconv_steps = 0, steps_run = 0, active_rows_sum = 0;
 
     // model selection (src/pj-learn.cpp:229-232)
     double auc_best = 0.0;
@@ -254,6 +254,12 @@ void step_finish(dlco_ctx *c)
     bool conv = true;
     c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
     if (!conv) c->nonconv_steps++;
+    {
+        int k = 0;                                       // rows that entered this rank's SYRK this step
+        d2h(c, &k, c->k_active.p, sizeof(int));
+        c->active_rows_sum += k;
+        c->steps_run++;
+    }
     c->t++;
     c->phase = 0;
 }
@@ -813,6 +819,14 @@ int dlco_profile_read(dlco_ctx *c, const char *kernel, int64_t *launches, double
         *launches = c->prof.rec[slot].n;
         *total_ms = c->prof.rec[slot].ms;
     });
+}
+
+int dlco_counters(const dlco_ctx *c, int64_t out[8])
+{
+    if (!c || !out) return DLCO_ERR_INVALID;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = c->steps_run; out[1] = c->active_rows_sum; out[2] = c->nonconv_steps;
+    return DLCO_OK;
 }
 
 int dlco_eig_stats(const dlco_ctx *c, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps, int32_t *block_rows)
