@@ -28,7 +28,7 @@ namespace {
 constexpr int TB = 128;           // tile edge
 constexpr int KB = 32;            // K depth per LDS stage
 constexpr int LD = TB + 4;        // LDS row pitch of the k-major images
-constexpr int TLD = TB + 1;       // pitch of the transpose buffer
+constexpr int TLD = TB + 4;       // pitch of the output re-layout buffer (16-byte aligned rows)
 constexpr int NTH = 256;
 
 struct SyrkDev {
@@ -123,8 +123,22 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         }
     };
 
+    if (nk > 0) load_ids(0);
+    // the tile's previous contents (dual average term) are fetched now and used in the epilogue:
+    // their HBM latency hides under the whole K loop
+    float oldv[2][2][16];
+    const bool use_old = (g.beta != 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int jl = wn * 64 + b * 32 + lr;
+                oldv[a][b][r] = use_old ? g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] : 0.f;
+            }
     if (nk > 0) {
-        load_ids(0);
         load_rows();
         if (nk > 1) load_ids(1);
         store_rows(0);
@@ -152,29 +166,41 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
     }
 
     // ---- epilogue: out = beta*old + alpha*acc on the upper tile; mirror below the diagonal -------
+    // All stores are 16 bytes per lane.  The transposed copy goes straight from the accumulator
+    // registers: a lane holds 4 consecutive rows of one column (regs 4g..4g+3), which are 4
+    // consecutive columns of the transposed row.  The tile itself is re-laid through LDS so
+    // that 32 lanes write one whole 512-byte row.
     const bool diag = (bi == bj);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < 2; b++) {
+            const int jl = wn * 64 + b * 32 + lr;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int jl = wn * 64 + b * 32 + lr;
-                const long idx = (long)(i0 + il) * g.ldc + (j0 + jl);
-                float o = 0.f;
-                if (!diag || jl >= il) {
-                    o = g.alpha * acc[a][b][r];
-                    if (g.beta != 0.f) o += g.beta * g.C[idx];
-                    g.C[idx] = o;
+            for (int q = 0; q < 4; q++) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = 4 * q + e;
+                    o[e] = g.alpha * acc[a][b][r] + g.beta * oldv[a][b][r];
                 }
-                lds.T[il][jl] = o;
+                const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;       // rows il0 .. il0+3
+                if (!diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) lds.T[il0 + e][jl] = o[e];
             }
+        }
     __syncthreads();
-    // transposed store: output row (j0 + jl), columns i0 + il; a wave writes whole 512-byte rows
-    for (int e = tid; e < TB * TB; e += NTH) {
-        const int jl = e / TB, il = e % TB;
-        if (diag ? (jl > il) : true) g.C[(long)(j0 + jl) * g.ldc + (i0 + il)] = lds.T[il][jl];
+    for (int f = tid; f < TB * (TB / 4); f += NTH) {
+        const int il = f / (TB / 4), c4 = (f % (TB / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&lds.T[il][c4]);
+        if (diag) {
+            // exact symmetry on diagonal tiles: the lower triangle takes the upper triangle's values
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (c4 + e < il) v[e] = lds.T[c4 + e][il];
+        }
+        *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + il) * g.ldc + (j0 + c4)]) = v;
     }
 }
 
