@@ -110,31 +110,47 @@ __global__ __launch_bounds__(256) void whitener_kernel(const float *evals, const
 // Left-looking Cholesky of a Gram matrix M (n <= 64) on one wave: lane i owns row i.
 // A row whose pivot drops below rel_thresh * M_jj lies (to fp32 accuracy) in the span of the
 // rows before it: it is marked dead (L_jj = 1, rest of the column 0) and later zeroed.
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// Lane i keeps row i of M and of L in registers (both loops fully unrolled, so every register
+// index is static); L_jk of the pivot row reaches the other lanes through v_readlane.
 __global__ __launch_bounds__(64) void chol64_kernel(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl,
                                                    int *dead)
 {
-    __shared__ float Ls[64][65];
     const int i = threadIdx.x;
-    for (int j = 0; j < n; j++) {
-        float s = 0.f;
-        if (i >= j && i < n) {
-            s = 0.5f * (M[(long)i * ldm + j] + M[(long)j * ldm + i]);
-            for (int k = 0; k < j; k++) s -= Ls[i][k] * Ls[j][k];
-        }
-        const float d = __shfl(s, j, 64);
-        const float mjj = M[(long)j * ldm + j];
-        const bool is_dead = !(d > rel_thresh * mjj) || !(mjj > 0.f);
-        if (i >= j && i < n) {
+    float Mr[64], Lr[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        Mr[k] = (i < n && k <= i && k < n) ? M[(long)i * ldm + k] : 0.f;     // lower triangle of the Gram matrix
+        Lr[k] = 0.f;
+    }
+    float diag = 1.f;
+#pragma unroll
+    for (int k = 0; k < 64; k++) diag = (k == i) ? Mr[k] : diag;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        if (j < n) {                                                           // wave-uniform
+            float s = (i >= j) ? Mr[j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= Lr[k] * lane_bcast(Lr[k], j);
+            const float d = lane_bcast(s, j);
+            const float mjj = lane_bcast(diag, j);
+            const bool is_dead = !(d > rel_thresh * mjj) || !(mjj > 0.f);
             float v;
             if (is_dead) v = (i == j) ? 1.f : 0.f;
             else v = (i == j) ? sqrtf(d) : s * rsqrtf(d);
-            Ls[i][j] = v;
+            Lr[j] = (i >= j && i < n) ? v : 0.f;
+            if (i == j) dead[j] = is_dead ? 1 : 0;
         }
-        if (i == j) dead[j] = is_dead ? 1 : 0;
-        __syncthreads();
     }
-    if (i < n)
-        for (int k = 0; k <= i; k++) L[(long)i * ldl + k] = Ls[i][k];
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 64; k++)
+            if (k <= i) L[(long)i * ldl + k] = Lr[k];
+    }
 }
 
 // Q = L^-1 Z for a panel of m <= 64 rows (forward substitution); thread f owns column f, so the
@@ -142,20 +158,22 @@ __global__ __launch_bounds__(64) void chol64_kernel(const float *M, long ldm, in
 __global__ __launch_bounds__(256) void trsm64_kernel(const float *L, long ldl, const int *dead, int m, const float *Z,
                                                     float *Q, long ld, int F)
 {
-    __shared__ float Ls[64][65];
-    __shared__ float qs[64][256];
-    __shared__ int dd[64];
-    for (int e = threadIdx.x; e < m * m; e += 256) { const int r = e / m, c = e % m; Ls[r][c] = (c <= r) ? L[(long)r * ldl + c] : 0.f; }
-    for (int e = threadIdx.x; e < m; e += 256) dd[e] = dead[e];
-    __syncthreads();
+    // the solved rows of this column stay in registers (loops fully unrolled: static indices);
+    // the coefficients L_ij are wave-uniform and come through the scalar cache
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
-    for (int i = 0; i < m; i++) {
-        float acc = Z[(long)i * ld + f];
-        for (int j = 0; j < i; j++) acc -= Ls[i][j] * qs[j][threadIdx.x];
-        const float q = dd[i] ? 0.f : acc / Ls[i][i];
-        qs[i][threadIdx.x] = q;
-        Q[(long)i * ld + f] = q;
+    float q[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i < m) {                                                          // wave-uniform
+            float acc = Z[(long)i * ld + f];
+#pragma unroll
+            for (int j = 0; j < i; j++) acc -= L[(long)i * ldl + j] * q[j];
+            q[i] = dead[i] ? 0.f : acc / L[(long)i * ldl + i];
+            Q[(long)i * ld + f] = q[i];
+        } else {
+            q[i] = 0.f;
+        }
     }
 }
 

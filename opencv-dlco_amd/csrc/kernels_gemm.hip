@@ -201,11 +201,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmDev g)
 __global__ void splitk_reduce_kernel(const float *slab, int split, int M, int N, float *C, long ldc, float alpha,
                                      float beta, const float *E1, float b1, const float *E2, float b2)
 {
+    // 16 lanes (one DPP row) per output element: lane z adds slices z, z+16, ... in order, the 16
+    // partial sums are combined by a fixed butterfly, so the result does not depend on timing.
     const long total = (long)M * N;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int zl = threadIdx.x & 15;
+    for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; e < total; e += ((long)gridDim.x * blockDim.x) >> 4) {
         const int i = (int)(e / N), j = (int)(e % N);
         float s = 0.f;
-        for (int z = 0; z < split; z++) s += slab[(long)z * total + e];   // fixed order: deterministic
+        for (int z = zl; z < split; z += 16) s += slab[(long)z * total + e];
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+        if (zl != 0) continue;
         const long idx = (long)i * ldc + j;
         float o = alpha * s;
         if (beta != 0.f) o += beta * C[idx];
@@ -456,8 +464,8 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
     DLCO_HIP(hipGetLastError());
     if (split > 1 && !a.raw_slab) {
         const long total = (long)a.M * a.N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        long blocks = (total * 16 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)a.slab, split, a.M, a.N,
                            a.C, a.ldc, a.alpha, a.beta, a.E1, a.b1, a.E2, a.b2);
         DLCO_HIP(hipGetLastError());
