@@ -38,6 +38,20 @@ def make_U(F, k, seed):
     return (U * decay[:, None]).astype(np.float32)
 
 
+def pmc_traffic(F, bl):
+    """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_syrk.json:
+    separate FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC
+    counters cannot be read inside a timed run, so the figure is the committed one; it is only
+    reported for the configuration it was measured on."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_syrk.json")))
+        if F == 8192 and bl == 200:
+            return d["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(ctx, F, B, mu, gamma, rows):
     """The oracle (reference loop order, OpenBLAS sgemm/ssyevr) timed on this box's host cores
     on a bounded sample: one full training step on a `rows`-row subset of the same data."""
@@ -79,6 +93,8 @@ def main():
     ap.add_argument("--latent", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
+    ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +118,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ddist = importlib.import_module("opencv-dlco_amd.dist")
-    ctx = dlco.Context(F, N, B=B, mu=args.mu, gamma=args.gamma, device=local_rank, rank=rank, world=world)
+    ctx = dlco.Context(F, N, B=B, mu=args.mu, gamma=args.gamma, device=local_rank, rank=rank, world=world,
+                       eig_guard=args.guard, eig_tol=args.eig_tol)
     dev_name, _, _ = ctx.device_name()
     U = make_U(F, args.latent, 2215 + 1)
     ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)        # identical bytes on every rank (dataset replicated)
@@ -180,7 +197,8 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
-            "traffic": None,
+            "traffic": pmc_traffic(F, Bl),
+            "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_syrk.json); algorithmic bytes 8*F*F + 4*K*F = %d" % int(8 * F * F + 4 * k_mean * F),
             "avg_launch_ms": ms_syrk / max(n_syrk, 1),
             "launches": n_syrk,
             "algorithmic_flops_per_launch": flops_launch,

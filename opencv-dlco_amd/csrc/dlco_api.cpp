@@ -243,12 +243,16 @@ void step_finish(dlco_ctx *c)
     }
     // E1/E2.  Cold tracker: the range of dfAvg after the first step is spanned by the batch rows,
     // so they seed the block (global batch: every rank holds the full row lists and counts).
+    // The positive eigen-directions of H = -dfAvg come from the negative pairs' outer products,
+    // so the negatives are listed first; at most 512 rows are used (with the reference's B = 200
+    // that is every row and the first Rayleigh-Ritz is exact; larger global batches start from
+    // a subspace and iterate).
     if (c->eig->block_rows() == 0) {
-        build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, c->B, 0, c->B, c->seed_ids.p, c->seed_w.p,
+        build_active_rows(c->neg_rows.p, c->pos_rows.p, c->kappa.p, c->rho.p, c->B, 0, c->B, c->seed_ids.p, c->seed_w.p,
                           c->k_active.p + 1, c->stream);
         int k = 0;
         d2h(c, &k, c->k_active.p + 1, sizeof(int));
-        if (k > 0) c->eig->seed_rows(c->dists, c->F, c->seed_ids.p, k);
+        if (k > 0) c->eig->seed_rows(c->dists, c->F, c->seed_ids.p, std::min(k, 512));
     }
     const float cscale = (float)(std::sqrt((double)c->t + 1.0) / (double)c->cfg.gamma);
     bool conv = true;
@@ -362,7 +366,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const size_t FF = (size_t)c->F * c->F;
         c->dfavg.alloc(FF); c->dfavg.zero(c->stream);
         c->grad.alloc(FF);
-        const int max_rows = std::max(1024, 2 * c->B + c->cfg.eig_guard);
+        const int max_rows = 1024;                               // block capacity (positive rank + guards)
         c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
         c->eig->set_profiler(&c->prof);
         c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));

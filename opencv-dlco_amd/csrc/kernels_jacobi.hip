@@ -95,6 +95,32 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
                 f32x4 *gq = reinterpret_cast<f32x4 *>(G + (long)(live ? q : 0) * ldc);
                 const int nch = ldc >> 2;
                 float a = 0.f, b = 0.f, c = 0.f;
+                if (nch <= 32) {
+                    // n <= 128: a lane owns at most two 16-byte chunks of each column and keeps them
+                    // in registers between the dot products and the rotation (one LDS read, one write)
+                    const bool h0 = live && sub < nch, h1 = live && sub + 16 < nch;
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 x0 = h0 ? gp[sub] : z4, y0 = h0 ? gq[sub] : z4;
+                    const f32x4 x1 = h1 ? gp[sub + 16] : z4, y1 = h1 ? gq[sub + 16] : z4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a += x0[e] * x0[e] + x1[e] * x1[e];
+                        b += y0[e] * y0[e] + y1[e] * y1[e];
+                        c += x0[e] * y0[e] + x1[e] * y1[e];
+                    }
+                    a = row16_sum(a); b = row16_sum(b); c = row16_sum(c);
+                    const float denom = sqrtf(a * b);
+                    const float off = (live && denom > 0.f) ? fabsf(c) / denom : 0.f;
+                    off_max = fmaxf(off_max, off);
+                    if (off > tol) {
+                        const float zeta = (b - a) / (2.f * c);
+                        const float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+                        const float cs = 1.f / sqrtf(1.f + t * t), sn = cs * t;
+                        if (h0) { gp[sub] = cs * x0 - sn * y0; gq[sub] = sn * x0 + cs * y0; }
+                        if (h1) { gp[sub + 16] = cs * x1 - sn * y1; gq[sub + 16] = sn * x1 + cs * y1; }
+                    }
+                    continue;
+                }
                 if (live)
                     for (int ch = sub; ch < nch; ch += 16) {
                         const f32x4 x = gp[ch], y = gq[ch];

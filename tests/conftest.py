@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+# torch ships its own HIP runtime; it must be the first one loaded in a process that also loads
+# libdlco.so, or torch later finds "No HIP GPUs" (two runtimes with one SONAME).  The product
+# itself never needs torch; only the multi-rank tests and bench.py --gpus N>1 do.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
