@@ -342,7 +342,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                 const double x = std::max(1.0, (double)(h_theta_[j] - c0) / e0);
                 const double amp = std::cosh((double)d * std::acosh(x));
                 if (j == start) amp0 = amp;
-                else if (j - start >= 64 || amp0 > 30.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
+                else if (j - start >= 64 || amp0 > 100.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
             }
             if (n_ritz < m_) panel_ends.push_back(n_ritz);
         }
@@ -418,7 +418,14 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     if (converged) *converged = conv;
 
     // ---- trim the block, emit W (ascending eigenvalue order, like LAPACK's) ----------------------
-    m_ = std::max(1, std::min(m_, nw + guard_));
+    {
+        // the products pad the block to a multiple of 32 rows: prefer a block that fills its
+        // padding exactly, as long as at least half of the guard vectors stay
+        int keep = nw + guard_;
+        const int r32 = (keep / 32) * 32;
+        if (r32 >= nw + std::max(4, guard_ / 2)) keep = r32;
+        m_ = std::max(1, std::min(m_, keep));
+    }
     double tr = 0.0;
     if (nw > 0) {
         h_sc_.resize(nw);

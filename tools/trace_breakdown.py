@@ -1,0 +1,17 @@
+import csv, collections, glob, re, sys
+f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rows = list(csv.DictReader(open(f)))
+syrk = [r for r in rows if 'syrk_rda' in r['Kernel_Name']]
+start = int(syrk[-nsteps]['Start_Timestamp'])
+t1 = max(int(r['End_Timestamp']) for r in rows)
+agg = collections.defaultdict(lambda: [0, 0])
+for r in rows:
+    if int(r['Start_Timestamp']) >= start:
+        m = re.search(r'(\w+_kernel(<[^>]*>)?|__amd_\w+)', r['Kernel_Name'])
+        k = m.group(1) if m else r['Kernel_Name'][:40]
+        agg[k][0] += 1; agg[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+tot = sum(v[1] for v in agg.values())
+print("wall ms/step %.3f  gpu busy ms/step %.3f  launches/step %.1f" % ((t1 - start) / nsteps / 1e6, tot / nsteps / 1e6, sum(v[0] for v in agg.values()) / nsteps))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+    print("%-36s calls/step %6.2f  us/call %8.1f  ms/step %.3f" % (k[:36], v[0] / nsteps, v[1] / v[0] / 1e3, v[1] / nsteps / 1e6))
