@@ -155,6 +155,12 @@ int dlco_grad_rda(dlco_ctx *ctx, const int32_t *pos_rows_host, const int32_t *ne
  * in eigenvalue, as LAPACK orders them) and optionally A+. */
 int dlco_psd_project(dlco_ctx *ctx, const float *dfavg_host, uint32_t t,
                      float *W_host, int32_t *r, float *A_host /* may be NULL */);
+/* Building block of E1 (no single reference line: the reference calls LAPACKE_ssyevr, :440):
+ * out[rows,F] = X[rows,F] * G[F,F] for a symmetric G, rows <= 128.  mode 0 = exact fp32 MFMA
+ * (used by the Rayleigh-Ritz step), mode 1 = split-bf16 MFMA with fp32 accumulation (used by
+ * the Chebyshev filter; relative error ~1e-5). */
+int dlco_sym_product(dlco_ctx *ctx, const float *X_host, int32_t rows, const float *G_host, int32_t mode,
+                     float *out_host);
 /* H1: sum_i sum_j max(pos_i + 1 - neg_j, 0)  (src/kernelop-opencv.cu:49-80). */
 int dlco_hinge_sum(dlco_ctx *ctx, const float *pos_host, int32_t n_pos,
                    const float *neg_host, int32_t n_neg, double *out);

@@ -103,6 +103,7 @@ def load():
     L.dlco_grad_rda.argtypes = [vp, i32p, i32p, i32p, i32p, C.c_int32, C.c_float, C.c_float, f32p, f32p]
     L.dlco_psd_project.argtypes = [vp, f32p, C.c_uint32, f32p, i32p, f32p]
     L.dlco_hinge_sum.argtypes = [vp, f32p, C.c_int32, f32p, C.c_int32, C.POINTER(C.c_double)]
+    L.dlco_sym_product.argtypes = [vp, f32p, C.c_int32, f32p, C.c_int32, f32p]
     L.dlco_roc_stats.argtypes = [vp, f32p, u8p, C.c_int32, f32p, C.POINTER(C.c_double)]
     L.dlco_log_step.argtypes = [vp, C.POINTER(LogEntry)]
     L.dlco_get_saved.argtypes = [vp, f32p, i32p, f32p]
@@ -322,6 +323,12 @@ class Context:
         r = C.c_int32()
         self._ck(self.L.dlco_psd_project(self.h, _p(d, f32p), t, _p(W, f32p), C.byref(r), _p(A, f32p)))
         return W[:r.value].copy(), A
+
+    def sym_product(self, X, G, mode=0):
+        x, g = _f32(X), _f32(G)
+        out = np.empty_like(x)
+        self._ck(self.L.dlco_sym_product(self.h, _p(x, f32p), x.shape[0], _p(g, f32p), mode, _p(out, f32p)))
+        return out
 
     def hinge_sum(self, pos, neg):
         p, n = _f32(pos), _f32(neg)

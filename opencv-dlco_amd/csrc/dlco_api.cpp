@@ -717,6 +717,33 @@ int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_
     });
 }
 
+int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float *G_host, int32_t mode, float *out_host)
+{
+    if (!c || !X_host || !G_host || !out_host || rows < 1 || rows > 128) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        const int F = c->F, pad = ((rows + 31) / 32) * 32;
+        DevBuf<float> X, G, out;
+        X.alloc((size_t)pad * F); G.alloc((size_t)F * F); out.alloc((size_t)pad * F);
+        X.zero(c->stream);
+        h2d(c, X.p, X_host, (size_t)rows * F * sizeof(float));
+        h2d(c, G.p, G_host, (size_t)F * F * sizeof(float));
+        bool ok;
+        if (mode == 1) {
+            DevBuf<char> hi, lo;
+            hi.alloc(bf16x2_plane_bytes(rows, F)); lo.alloc(bf16x2_plane_bytes(rows, F));
+            DevBuf<float> slab;
+            slab.alloc(bf16x2_slab_floats(rows, F));
+            ok = skinny_product_bf16x2(X.p, F, rows, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, hi.p, lo.p, slab.p, c->stream);
+            sync(c);
+        } else {
+            ok = skinny_product_f32(X.p, F, rows, pad, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, c->stream);
+        }
+        DLCO_CHECK(ok, DLCO_ERR_INVALID, "dlco_sym_product: shape not supported by this mode");
+        d2h(c, out_host, out.p, (size_t)rows * F * sizeof(float));
+    });
+}
+
 int dlco_hinge_sum(dlco_ctx *c, const float *pos_host, int32_t n_pos, const float *neg_host, int32_t n_neg, double *out)
 {
     if (!c || !out || n_pos < 0 || n_neg < 0) return DLCO_ERR_INVALID;

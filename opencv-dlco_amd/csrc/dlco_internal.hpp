@@ -130,6 +130,14 @@ struct GemmArgs {
 };
 
 void gemm_f32(const GemmArgs &a, hipStream_t s);
+// Same product on the bf16 matrix cores with split operands (x = hi + lo, three MFMAs per term,
+// fp32 accumulation; ~1e-5 relative error): kernels_bf16x2.hip.  plane_hi/lo are workspaces of
+// bf16x2_plane_bytes(M, K) bytes each.  Returns false for unsupported shapes.
+size_t bf16x2_plane_bytes(int M, int K);
+size_t bf16x2_slab_floats(int M, int N);
+bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
+                           long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
+                           float *slab, hipStream_t s);
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).
@@ -140,6 +148,8 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, 
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,
                         float alpha, float *C, long ldc, const float *E1, float b1, const float *E2, float b2, hipStream_t s);
 size_t gemm_slab_floats(int M, int N, int split_k);
+void splitk_reduce_f32(const float *slab, int split, int M, int N, float *C, long ldc, float alpha, float beta,
+                       const float *E1, float b1, const float *E2, float b2, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // step kernels (kernels_step.hip)

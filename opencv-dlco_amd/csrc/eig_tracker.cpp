@@ -29,6 +29,12 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     jwork_.alloc(jacobi_work_floats(cap_));
     ibuf_.alloc(8);
     dead_.alloc(64);
+    // filter products run on the bf16 matrix cores with split operands unless DLCO_FP32_FILTER is set
+    bf16_filter_ = (F_ % 512 == 0) && std::getenv("DLCO_FP32_FILTER") == nullptr;
+    if (bf16_filter_) {
+        plane_hi_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
+        plane_lo_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
+    }
     pv_.alloc(F_);
     pw_.alloc(F_);
     slab_floats_ = std::max((size_t)4 * cap_ * F_, (size_t)8 << 20);
@@ -90,9 +96,16 @@ void EigTracker::append_random(float *Q, int have, int add)
 
 // out[rows][F] = alpha * X*G + b1*E1 + b2*E2     (G symmetric F x F)
 void EigTracker::product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
-                         const float *E2, float b2)
+                         const float *E2, float b2, bool approx)
 {
     st_.product_rows += rows;
+    if (approx && bf16_filter_ && rows <= 128 && F_ >= 256) {
+        if (prof_) prof_->begin(PROF_EIG_PRODUCT);
+        const bool ok = skinny_product_bf16x2(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p,
+                                              plane_lo_.p, slab_.p, s_);
+        if (prof_) prof_->end(PROF_EIG_PRODUCT);
+        if (ok) return;
+    }
     if (rows <= 128 && F_ >= 256) {
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         skinny_product_f32(X, F_, rows, cap_, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, s_);
@@ -328,10 +341,10 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             d = std::max(2, std::min(d, dcap));
             const float *prev = Q_;
             float *cur = pick({Q_});
-            product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f);
+            product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f, true);
             for (int k = 2; k <= d; k++) {
                 float *nxt = pick({prev, cur});
-                product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f);
+                product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f, true);
                 prev = cur; cur = nxt;
             }
             Z = cur;
@@ -352,7 +365,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         float *Qo = Z;
         orthonormalize(Z, m_, nullptr, panel_ends);                  // in place
         float *Yb = pick({Qo});
-        product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f);            // Yb = Qo * H
+        product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f, false);     // Yb = Qo * H, exact fp32
         gram(Yb, Qo, m_, Tm_.p);
         if (prof_) prof_->begin(PROF_JACOBI);
         jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);

@@ -43,7 +43,7 @@ public:
 
 private:
     void product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
-                 const float *E2, float b2);
+                 const float *E2, float b2, bool approx);
     void gram(const float *X, const float *Y, int rows, float *T);
     void gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T);
     void project_out(float *Wp, int np, const float *Q, int kept);
@@ -75,6 +75,8 @@ private:
     DevBuf<float> Tm_, Vm_, Cw_, evals_, res_, jwork_, slab_, pv_, pw_, scale_;
     DevBuf<int32_t> srcrow_;
     DevBuf<int> ibuf_;               // [0] kept count, [1] sweeps
+    bool bf16_filter_ = false;       // filter products as split-bf16 MFMA (kernels_bf16x2.hip)
+    DevBuf<char> plane_hi_, plane_lo_;
     DevBuf<int> dead_;               // dead-row flags of the panel being factored
     size_t slab_floats_ = 0;
     std::vector<float> h_theta_, h_res_, h_tmp_, h_sc_;

@@ -161,6 +161,28 @@ def test_grad_rda_fused_kernel(dlco, ref, F, B, zero_frac):
     ctx.close()
 
 
+@pytest.mark.parametrize("F,rows", [(256, 7), (512, 96), (1024, 128), (384, 40)])
+def test_tracker_product_kernels(dlco, F, rows):
+    """The two product kernels of the eigen tracker against fp64: exact-fp32 MFMA (Rayleigh-Ritz
+    step) and split-bf16 MFMA (Chebyshev filter only; stated error budget 3e-5 of |X||G|)."""
+    rng = np.random.default_rng(F + rows)
+    G = rng.standard_normal((F, F)).astype(np.float32)
+    G = ((G + G.T) * 0.5).astype(np.float32)
+    X = rng.standard_normal((rows, F)).astype(np.float32)
+    X[0, :] = 0.0
+    X[-1, 3] = 1e-3
+    want = X.astype(np.float64) @ G.astype(np.float64)
+    scale = np.abs(X).astype(np.float64) @ np.abs(G).astype(np.float64)      # sum of |terms| per output
+    ctx = dlco.Context(F, 16, B=4)
+    got32 = ctx.sym_product(X, G, mode=0)
+    assert (np.abs(got32 - want) <= 2e-6 * scale + 1e-30).all()
+    if F % 512 == 0:
+        got16 = ctx.sym_product(X, G, mode=1)
+        assert (np.abs(got16 - want) <= 3e-5 * scale + 1e-30).all()
+        assert np.abs(got16 - want).max() > 0                                  # it really is the approximate path
+    ctx.close()
+
+
 def test_hinge_sum(small, ref):
     ctx = small[0]
     rng = np.random.default_rng(11)
