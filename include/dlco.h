@@ -68,6 +68,15 @@ int dlco_set_data(dlco_ctx *ctx, const float *dists_host, const uint8_t *labels_
 /* Same, but `dists_dev` already lives in device memory and is adopted, not copied
  * (it must stay valid for the life of the context). */
 int dlco_set_data_device(dlco_ctx *ctx, const float *dists_dev, const uint8_t *labels_host);
+/* Pair mode: instead of the N x F "Distance" matrix that comp-uprjdists materialises
+ * (Dist = Desc1 - Desc2 per pair, src/comp-uprjdists.cpp:308-327; 16 GB for 500k x 8192)
+ * the caller uploads the P per-patch descriptors desc_host [P,F] once and the pair table
+ * pairs_host [N,4] = (patchID1, 3DpointID1, patchID2, 3DpointID2) of the reference's
+ * "Indices" dataset.  Row i of the training matrix is desc[pairs[i][0]] - desc[pairs[i][2]],
+ * formed in fp32 inside the kernels (the same single rounding as the reference's Mat
+ * subtraction); Label[i] = (pairs[i][1] == pairs[i][3]), src/comp-uprjdists.cpp:268-272.
+ * Every result is bit-identical to dlco_set_data on the pre-differenced matrix. */
+int dlco_set_pairs(dlco_ctx *ctx, const float *desc_host, int32_t P, const int32_t *pairs_host);
 /* Bench helper (no reference counterpart: the Brown/Winder sets are not redistributable):
  * fills the context's Distance matrix in HBM with d = U^T z + noise*eps clipped to [-1,1],
  * label = 1 for even rows; U is [k,F] on the host. */

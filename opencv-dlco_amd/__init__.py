@@ -81,6 +81,7 @@ def load():
     L.dlco_device_name.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dlco_set_data.argtypes = [vp, f32p, u8p]
     L.dlco_set_data_device.argtypes = [vp, vp, u8p]
+    L.dlco_set_pairs.argtypes = [vp, f32p, C.c_int32, i32p]
     L.dlco_synth_data.argtypes = [vp, f32p, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_float]
     L.dlco_get_rows.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.dlco_get_index.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p]
@@ -187,6 +188,12 @@ class Context:
     def set_data_device(self, dev_ptr, labels):
         l = np.ascontiguousarray(labels, np.uint8).ravel()
         self._ck(self.L.dlco_set_data_device(self.h, C.c_void_p(dev_ptr), _p(l, u8p)))
+
+    def set_pairs(self, desc, pairs):
+        """Pair mode: per-patch descriptors [P,F] + the [N,4] Indices table (see dlco_set_pairs)."""
+        d, q = _f32(desc), _i32(pairs)
+        assert d.ndim == 2 and d.shape[1] == self.F and q.shape == (self.N, 4)
+        self._ck(self.L.dlco_set_pairs(self.h, _p(d, f32p), d.shape[0], _p(q, i32p)))
 
     def synth_data(self, U, seed, sigma_pos, sigma_neg, noise):
         U = _f32(U)

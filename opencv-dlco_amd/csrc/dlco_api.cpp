@@ -31,6 +31,12 @@ struct dlco_ctx {
     PairIndex idx;
     DevBuf<int32_t> val_pos_ids, val_neg_ids;
     bool have_data = false;
+    // pair mode (dlco_set_pairs): `dists` holds the P per-patch descriptors and row i of the
+    // training matrix is dists[pair_a[i]] - dists[pair_b[i]], formed inside the kernels
+    bool pair_mode = false;
+    int P = 0;
+    DevBuf<int32_t> pair_a, pair_b, tr_a, tr_b;
+    size_t tr_cap = 0;
 
     // training state
     CvRng rng{2215};
@@ -114,19 +120,39 @@ void finish_data(dlco_ctx *c, const uint8_t *labels_host)
     c->have_data = true;
 }
 
+// Where the kernels find training rows `ids_dev[0..n)` (or rows base..base+n when ids_dev is
+// NULL).  Row mode: the ids themselves.  Pair mode: two descriptor-row lists whose difference is
+// the training row (src/comp-uprjdists.cpp:327); a listed selection is translated on the stream
+// into the scratch lists, which stay valid until the next call.
+struct RowRef { const int32_t *a, *b; };
+
+RowRef rows_of(dlco_ctx *c, const int32_t *ids_dev, int base, int n)
+{
+    if (!c->pair_mode) return {ids_dev, nullptr};
+    if (!ids_dev) return {c->pair_a.p + base, c->pair_b.p + base};
+    if ((size_t)n > c->tr_cap) {
+        sync(c);
+        c->tr_cap = (size_t)std::max(n, 4096);
+        c->tr_a.alloc(c->tr_cap); c->tr_b.alloc(c->tr_cap);
+    }
+    translate_ids(ids_dev, 0, n, c->pair_a.p, c->pair_b.p, c->tr_a.p, c->tr_b.p, c->stream);
+    return {c->tr_a.p, c->tr_b.p};
+}
+
 // dist[i] = |W x_{row(i)}|^2 for many rows (validation / statistics): chunked GEMM, fused square-sum
 void project_many(dlco_ctx *c, const int32_t *ids_dev, int row0, int n, const float *Wd, int r, float *out_dev)
 {
     if (n <= 0) return;
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
     c->vproj.alloc((size_t)r * VCHUNK);
+    const RowRef rr = rows_of(c, ids_dev, row0, n);
     for (int c0 = 0; c0 < n; c0 += VCHUNK) {
         const int nc = std::min(VCHUNK, n - c0);
         GemmArgs g;
         g.M = r; g.N = nc; g.K = c->F;
         g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
         g.B.ld = c->F; g.B.kmajor = false;
-        if (ids_dev) { g.B.p = c->dists; g.B.row_ids = ids_dev + c0; }
+        if (rr.a) { g.B.p = c->dists; g.B.row_ids = rr.a + c0; g.B.row_ids2 = rr.b ? rr.b + c0 : nullptr; }
         else g.B.p = c->dists + (size_t)(row0 + c0) * c->F;
         g.C = c->vproj.p; g.ldc = VCHUNK;
         gemm_f32(g, c->stream);
@@ -148,7 +174,8 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
     GemmArgs g;
     g.M = r; g.N = n; g.K = c->F;
     g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
-    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = false; g.B.row_ids = ids_dev;
+    const RowRef rr = rows_of(c, ids_dev, 0, n);
+    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = false; g.B.row_ids = rr.a; g.B.row_ids2 = rr.b;
     g.C = proj; g.ldc = n;
     g.split_k = (int)split; g.slab = c->proj_slab.p;
     c->prof.begin(PROF_PROJECT);
@@ -161,18 +188,20 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
 void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev, int kmax, float alpha, float beta,
                float *dst)
 {
+    const int kpad = (kmax + 31) & ~31;                 // the lists are zero padded up to here
+    const RowRef rr = rows_of(c, ids, 0, kpad);
     // fused, symmetric, branch-free kernel when the shape allows it (F a multiple of 128)
     if (c->F % 128 == 0 && (reinterpret_cast<uintptr_t>(c->dists) & 15) == 0) {
         c->prof.begin(PROF_GRAD_SYRK);
-        const bool done = syrk_rda_f32(c->dists, c->F, ids, w, k_dev, (kmax + 31) & ~31, c->F, alpha, beta, dst, c->F, c->stream);
+        const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;
     }
     GemmArgs g;
     g.M = c->F; g.N = c->F; g.K = kmax;
-    g.A.p = c->dists; g.A.ld = c->F; g.A.kmajor = true; g.A.row_ids = ids; g.A.row_scale = w;
-    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = true; g.B.row_ids = ids;
+    g.A.p = c->dists; g.A.ld = c->F; g.A.kmajor = true; g.A.row_ids = rr.a; g.A.row_ids2 = rr.b; g.A.row_scale = w;
+    g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = true; g.B.row_ids = rr.a; g.B.row_ids2 = rr.b;
     g.C = dst; g.ldc = c->F;
     g.alpha = alpha; g.beta = beta;
     g.k_dev = k_dev;
@@ -252,7 +281,11 @@ void step_finish(dlco_ctx *c)
                           c->k_active.p + 1, c->stream);
         int k = 0;
         d2h(c, &k, c->k_active.p + 1, sizeof(int));
-        if (k > 0) c->eig->seed_rows(c->dists, c->F, c->seed_ids.p, std::min(k, 512));
+        if (k > 0) {
+            const int ks = std::min(k, 512);
+            const RowRef rr = rows_of(c, c->seed_ids.p, 0, ks);
+            c->eig->seed_rows(c->dists, c->F, rr.a, ks, rr.b);
+        }
     }
     const float cscale = (float)(std::sqrt((double)c->t + 1.0) / (double)c->cfg.gamma);
     bool conv = true;
@@ -416,7 +449,35 @@ int dlco_set_data(dlco_ctx *c, const float *dists_host, const uint8_t *labels_ho
         c->dists_own.alloc((size_t)c->N * c->F);
         h2d(c, c->dists_own.p, dists_host, (size_t)c->N * c->F * sizeof(float));
         c->dists = c->dists_own.p;
+        c->pair_mode = false;
         finish_data(c, labels_host);
+    });
+}
+
+// Pair mode: the caller hands over the P per-patch descriptors and the [N,4] pair table
+// (patchID1, 3DpointID1, patchID2, 3DpointID2: src/comp-uprjdists.cpp:268-269,308-314) instead of
+// the N x F matrix of differences that comp-uprjdists writes to the "Distance" dataset.
+int dlco_set_pairs(dlco_ctx *c, const float *desc_host, int32_t P, const int32_t *pairs_host)
+{
+    if (!c || !desc_host || !pairs_host || P < 1) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        std::vector<int32_t> a(c->N), b(c->N);
+        std::vector<uint8_t> lab(c->N);
+        for (int i = 0; i < c->N; i++) {
+            const int32_t *q = pairs_host + (size_t)i * 4;
+            DLCO_CHECK(q[0] >= 0 && q[0] < P && q[2] >= 0 && q[2] < P, DLCO_ERR_INVALID, "dlco_set_pairs: patch id out of range");
+            a[i] = q[0]; b[i] = q[2];
+            lab[i] = (q[1] == q[3]) ? 1 : 0;                       // src/comp-uprjdists.cpp:268-272
+        }
+        c->dists_own.alloc((size_t)P * c->F);
+        h2d(c, c->dists_own.p, desc_host, (size_t)P * c->F * sizeof(float));
+        c->dists = c->dists_own.p;
+        c->pair_a.alloc(c->N); c->pair_b.alloc(c->N);
+        h2d(c, c->pair_a.p, a.data(), (size_t)c->N * sizeof(int32_t));
+        h2d(c, c->pair_b.p, b.data(), (size_t)c->N * sizeof(int32_t));
+        c->pair_mode = true; c->P = P;
+        finish_data(c, lab.data());
     });
 }
 
@@ -426,6 +487,7 @@ int dlco_set_data_device(dlco_ctx *c, const float *dists_dev, const uint8_t *lab
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         c->dists = dists_dev;
+        c->pair_mode = false;
         finish_data(c, labels_host);
     });
 }
@@ -443,6 +505,7 @@ int dlco_synth_data(dlco_ctx *c, const float *U_host, int32_t k, uint64_t seed, 
         synth_rows(c->dists_own.p, c->N, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, c->stream);
         sync(c);
         c->dists = c->dists_own.p;
+        c->pair_mode = false;
         std::vector<uint8_t> lab(c->N);
         for (int i = 0; i < c->N; i++) lab[i] = (i % 2 == 0) ? 1 : 0;
         finish_data(c, lab.data());
@@ -454,6 +517,13 @@ int dlco_get_rows(dlco_ctx *c, int32_t row0, int32_t n, float *out_host)
     if (!c || !out_host) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         DLCO_CHECK(c->have_data && row0 >= 0 && n >= 0 && row0 + n <= c->N, DLCO_ERR_INVALID, "dlco_get_rows: range");
+        if (c->pair_mode) {                                // materialise the differences of the asked rows
+            DevBuf<float> tmp;
+            tmp.alloc((size_t)std::max(n, 1) * c->F);
+            scale_rows(tmp.p, c->F, c->dists, c->F, nullptr, c->pair_a.p + row0, n, c->F, c->stream, c->pair_b.p + row0);
+            d2h(c, out_host, tmp.p, (size_t)n * c->F * sizeof(float));
+            return;
+        }
         d2h(c, out_host, c->dists + (size_t)row0 * c->F, (size_t)n * c->F * sizeof(float));
     });
 }

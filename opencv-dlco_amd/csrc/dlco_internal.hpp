@@ -108,6 +108,7 @@ struct GemmOperand {
     long ld = 0;
     bool kmajor = false;
     const int32_t *row_ids = nullptr;
+    const int32_t *row_ids2 = nullptr;  // optional: the operand row is p[row_ids[x]] - p[row_ids2[x]] (pair mode)
     const float *row_scale = nullptr;   // only for k-major operands
 };
 
@@ -141,8 +142,9 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).
-bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, const int *k_dev, int kmax, int F,
-                  float alpha, float beta, float *C, long ldc, hipStream_t s);
+// ids2 != nullptr (pair mode): row k is D[ids[k]] - D[ids2[k]], formed on the fly.
+bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s);
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,
@@ -169,7 +171,10 @@ void sum_f32_to_f64(const float *x, int n, double *out, hipStream_t s);
 void trace_f64(const float *A, int F, long ld, double *out, hipStream_t s);
 void axpby_inplace(float *y, const float *x, float a, float b, size_t n, hipStream_t s);  // y = a*y + b*x
 void scale_rows(float *dst, long ldd, const float *src, long lds, const float *scale, const int32_t *src_rows,
-                int rows, int cols, hipStream_t s);                                        // dst[i] = scale[i]*src[src_rows[i]]
+                int rows, int cols, hipStream_t s, const int32_t *src_rows2 = nullptr);    // dst[i] = scale[i]*(src[src_rows[i]] - src[src_rows2[i]])
+// out_a[i] = pa[ids ? ids[i] : base + i], out_b likewise: row ids -> (patch, patch) ids of the pair table
+void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb, int32_t *out_a, int32_t *out_b,
+                   hipStream_t s);
 void fill_f32(float *p, float v, size_t n, hipStream_t s);
 
 // synthetic stand-in for a *-unproj.h5 generated in HBM (bench): d = U^T z + eps, clipped

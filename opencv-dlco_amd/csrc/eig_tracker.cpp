@@ -70,12 +70,12 @@ void EigTracker::reset()
     steps_since_lo_ = 0;
 }
 
-void EigTracker::seed_rows(const float *src, long ld, const int32_t *ids_dev, int n)
+void EigTracker::seed_rows(const float *src, long ld, const int32_t *ids_dev, int n, const int32_t *ids2_dev)
 {
     const int k = std::min(n, cap_);
     have_theta_ = false;
     if (k <= 0) { m_ = 0; return; }
-    scale_rows(Q_, F_, src, ld, nullptr, ids_dev, k, F_, s_);
+    scale_rows(Q_, F_, src, ld, nullptr, ids_dev, k, F_, s_, ids2_dev);
     m_ = k;
 }
 

@@ -28,8 +28,9 @@ public:
 
     // Forget the subspace (next update seeds from `seed_rows` or random vectors).
     void reset();
-    // Seed the block with `n` rows gathered from a device matrix (ids may be NULL = rows 0..n-1).
-    void seed_rows(const float *src, long ld, const int32_t *ids_dev, int n);
+    // Seed the block with `n` rows gathered from a device matrix (ids may be NULL = rows 0..n-1;
+    // with ids2 the seed row is src[ids] - src[ids2], the pair mode's descriptor difference).
+    void seed_rows(const float *src, long ld, const int32_t *ids_dev, int n, const int32_t *ids2_dev = nullptr);
 
     // Track the eigenpairs of H = -G above mu.  cscale = sqrt(t+1)/gamma.
     // Writes W [r][F] (rows sqrt(cscale*(theta-mu)) * q, ascending like LAPACK) and returns r.

@@ -26,7 +26,23 @@ struct OperandDev {
     const int32_t *row_ids;
     const float *row_scale;
     int vec_ok;
+    const int32_t *row_ids2;      // pair mode: operand row = p[row_ids[x]] - p[row_ids2[x]]
 };
+
+// up to 4 consecutive floats starting at src, elements at or beyond `limit - pos` are zero
+__device__ __forceinline__ f32x4 load4(const float *src, int pos, int limit, int vec_ok)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec_ok && pos + 3 < limit) {
+        v = *reinterpret_cast<const f32x4 *>(src);
+    } else {
+        v[0] = src[0];
+        if (pos + 1 < limit) v[1] = src[1];
+        if (pos + 2 < limit) v[2] = src[2];
+        if (pos + 3 < limit) v[3] = src[3];
+    }
+    return v;
+}
 
 struct GemmDev {
     int M, N, K;
@@ -57,15 +73,8 @@ __device__ __forceinline__ void load_tile(const OperandDev &op, int t0, int tmax
             const int k = k0 + row, col = t0 + c4 * 4;
             if (k < kend && col < tmax) {
                 const long mr = op.row_ids ? (long)op.row_ids[k] : (long)k;
-                const float *src = op.p + mr * op.ld + col;
-                if (op.vec_ok && col + 3 < tmax) {
-                    v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
-                    v[0] = src[0];
-                    if (col + 1 < tmax) v[1] = src[1];
-                    if (col + 2 < tmax) v[2] = src[2];
-                    if (col + 3 < tmax) v[3] = src[3];
-                }
+                v = load4(op.p + mr * op.ld + col, col, tmax, op.vec_ok);
+                if (op.row_ids2) v -= load4(op.p + (long)op.row_ids2[k] * op.ld + col, col, tmax, op.vec_ok);
                 if (op.row_scale) {
                     const float sc = op.row_scale[k];
                     v *= sc;
@@ -76,15 +85,8 @@ __device__ __forceinline__ void load_tile(const OperandDev &op, int t0, int tmax
             const int t = t0 + row, k = k0 + kq * 4;
             if (t < tmax && k < kend) {
                 const long mr = op.row_ids ? (long)op.row_ids[t] : (long)t;
-                const float *src = op.p + mr * op.ld + k;
-                if (op.vec_ok && k + 3 < kend) {
-                    v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
-                    v[0] = src[0];
-                    if (k + 1 < kend) v[1] = src[1];
-                    if (k + 2 < kend) v[2] = src[2];
-                    if (k + 3 < kend) v[3] = src[3];
-                }
+                v = load4(op.p + mr * op.ld + k, k, kend, op.vec_ok);
+                if (op.row_ids2) v -= load4(op.p + (long)op.row_ids2[t] * op.ld + k, k, kend, op.vec_ok);
             }
         }
         regs[u] = v;
@@ -441,8 +443,8 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
     DLCO_CHECK(!(a.upper_only && (a.M != a.N || a.split_k > 1)), -2, "gemm_f32: upper_only needs M==N, split_k==1");
     GemmDev g;
     g.M = a.M; g.N = a.N; g.K = a.K;
-    g.A = {a.A.p, a.A.ld, a.A.row_ids, a.A.kmajor ? a.A.row_scale : nullptr, vec_ok(a.A)};
-    g.B = {a.B.p, a.B.ld, a.B.row_ids, a.B.kmajor ? a.B.row_scale : nullptr, vec_ok(a.B)};
+    g.A = {a.A.p, a.A.ld, a.A.row_ids, a.A.kmajor ? a.A.row_scale : nullptr, vec_ok(a.A), a.A.row_ids2};
+    g.B = {a.B.p, a.B.ld, a.B.row_ids, a.B.kmajor ? a.B.row_scale : nullptr, vec_ok(a.B), a.B.row_ids2};
     g.C = a.C; g.ldc = a.ldc;
     g.alpha = a.alpha; g.beta = a.beta; g.E1 = a.E1; g.b1 = a.b1; g.E2 = a.E2; g.b2 = a.b2;
     g.k_dev = a.k_dev;

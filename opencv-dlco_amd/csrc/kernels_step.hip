@@ -160,13 +160,28 @@ __global__ void fill_kernel(float *p, float v, size_t n)
 }
 
 __global__ void scale_rows_kernel(float *dst, long ldd, const float *src, long lds, const float *scale,
-                                  const int32_t *src_rows, int rows, int cols)
+                                  const int32_t *src_rows, const int32_t *src_rows2, int rows, int cols)
 {
     const int i = blockIdx.x;
     if (i >= rows) return;
     const long sr = src_rows ? (long)src_rows[i] : (long)i;
     const float sc = scale ? scale[i] : 1.0f;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(long)i * ldd + c] = sc * src[sr * lds + c];
+    if (src_rows2) {      // pair mode: the row is a difference of two descriptor rows
+        const long sr2 = (long)src_rows2[i];
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(long)i * ldd + c] = sc * (src[sr * lds + c] - src[sr2 * lds + c]);
+    } else {
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(long)i * ldd + c] = sc * src[sr * lds + c];
+    }
+}
+
+__global__ void translate_ids_kernel(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb,
+                                     int32_t *out_a, int32_t *out_b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = ids ? ids[i] : base + i;
+    out_a[i] = pa[r];
+    out_b[i] = pb[r];
 }
 
 // ---- synthetic data ---------------------------------------------------------------------------
@@ -268,10 +283,19 @@ void fill_f32(float *p, float v, size_t n, hipStream_t s)
 }
 
 void scale_rows(float *dst, long ldd, const float *src, long lds, const float *scale, const int32_t *src_rows,
-                int rows, int cols, hipStream_t s)
+                int rows, int cols, hipStream_t s, const int32_t *src_rows2)
 {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, scale, src_rows, rows, cols);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, scale, src_rows, src_rows2, rows,
+                       cols);
+    DLCO_HIP(hipGetLastError());
+}
+
+void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb, int32_t *out_a, int32_t *out_b,
+                   hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(translate_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, base, n, pa, pb, out_a, out_b);
     DLCO_HIP(hipGetLastError());
 }
 

@@ -35,6 +35,7 @@ struct SyrkDev {
     const float *D;
     long ldd;
     const int32_t *ids;
+    const int32_t *ids2;          // pair mode: row k = D[ids[k]] - D[ids2[k]] (src/comp-uprjdists.cpp:327), else nullptr
     const float *w;
     const int *k_dev;             // device-resident active row count
     int kmax;                     // capacity of ids/w (multiple of KB, zero padded)
@@ -50,6 +51,7 @@ union SyrkLds {
     float T[TB][TLD];                                          // 66,048 B
 };
 
+template <bool PAIR>
 __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 
     // loader mapping: 4 float4 per operand per thread; f = tid + 256u -> row = f / 32, c4 = f % 32
     const int c4 = tid & 31, rbase = tid >> 5;    // rows rbase, rbase + 8, rbase + 16, rbase + 24
-    int32_t id_nx[4];
+    int32_t id_nx[4], id2_nx[4];
     float w_nx[4];
     f32x4 ra[4], rb[4];
 
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         for (int u = 0; u < 4; u++) {
             const int k = kt * KB + rbase + 8 * u;
             id_nx[u] = g.ids[k];
+            if (PAIR) id2_nx[u] = g.ids2[k];
             w_nx[u] = g.w[k];
         }
     };
@@ -111,6 +114,11 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
             const float *row = g.D + (long)id_nx[u] * g.ldd;
             f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
             f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
+            if (PAIR) {                                       // descriptor difference formed on the fly
+                const float *row2 = g.D + (long)id2_nx[u] * g.ldd;
+                xa -= *reinterpret_cast<const f32x4 *>(row2 + i0 + c4 * 4);
+                xb -= *reinterpret_cast<const f32x4 *>(row2 + j0 + c4 * 4);
+            }
             ra[u] = xa * w_nx[u];
             rb[u] = xb;
         }
@@ -206,15 +214,16 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 
 }  // namespace
 
-bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const float *w, const int *k_dev, int kmax, int F,
-                  float alpha, float beta, float *C, long ldc, hipStream_t s)
+bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
     SyrkDev g;
-    g.D = D; g.ldd = ldd; g.ids = ids; g.w = w; g.k_dev = k_dev; g.kmax = kmax; g.F = F;
+    g.D = D; g.ldd = ldd; g.ids = ids; g.ids2 = ids2; g.w = w; g.k_dev = k_dev; g.kmax = kmax; g.F = F;
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
     const int ntiles = g.nt * (g.nt + 1) / 2;
-    hipLaunchKernelGGL(syrk_rda_kernel, dim3(ntiles), dim3(NTH), 0, s, g);
+    if (ids2) hipLaunchKernelGGL(syrk_rda_kernel<true>, dim3(ntiles), dim3(NTH), 0, s, g);
+    else hipLaunchKernelGGL(syrk_rda_kernel<false>, dim3(ntiles), dim3(NTH), 0, s, g);
     DLCO_HIP(hipGetLastError());
     return true;
 }

@@ -377,3 +377,87 @@ def test_full_width_properties(dlco):
     want = ((rows.astype(np.float64) @ W.T.astype(np.float64)) ** 2).sum(1)
     assert np.abs(d - want).max() <= 1e-4 * want.max()
     ctx.close()
+
+
+def _pair_case(N, F, P, seed):
+    """Per-patch descriptors + the reference's [N,4] Indices table (patchID1, 3DpointID1,
+    patchID2, 3DpointID2; src/comp-uprjdists.cpp:268-269,308-314) and the matrix of
+    differences that comp-uprjdists would have written for it."""
+    rng = np.random.default_rng(seed)
+    point = rng.integers(0, P // 3, P).astype(np.int32)              # 3-D point of each patch
+    centre = rng.standard_normal((P // 3, F)).astype(np.float32) * 0.3
+    desc = np.clip(centre[point] + 0.12 * rng.standard_normal((P, F)).astype(np.float32), -1, 1).astype(np.float32)
+    a = rng.integers(0, P, N).astype(np.int32)
+    b = rng.integers(0, P, N).astype(np.int32)
+    # make about half of the pairs matches
+    same = rng.random(N) < 0.5
+    by_point = [np.flatnonzero(point == q) for q in range(P // 3)]
+    for i in np.flatnonzero(same):
+        cand = by_point[point[a[i]]]
+        b[i] = cand[rng.integers(0, cand.size)]
+    pairs = np.stack([a, point[a], b, point[b]], axis=1).astype(np.int32)
+    D = (desc[a] - desc[b]).astype(np.float32)                        # Dist = Desc1 - Desc2, :327
+    L = (pairs[:, 1] == pairs[:, 3]).astype(np.uint8)
+    return desc, pairs, D, L
+
+
+@pytest.mark.parametrize("F,B", [(256, 40), (96, 24)])               # fused SYRK path / generic GEMM path
+def test_pair_mode_bit_identical_to_row_mode(dlco, F, B):
+    """dlco_set_pairs (descriptors + Indices, differences formed inside the kernels) against
+    dlco_set_data on the pre-differenced matrix: every output must be the same bits."""
+    N, P = 3000, 900
+    desc, pairs, D, L = _pair_case(N, F, P, seed=5)
+    mu, gamma = 0.004, 0.5
+    row = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    row.set_data(D, L)
+    par = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    par.set_pairs(desc, pairs)
+    assert np.array_equal(par.get_rows(17, 40), D[17:57])
+    ia, ib = row.index(), par.index()
+    assert np.array_equal(ia["pos"], ib["pos"]) and np.array_equal(ia["neg"], ib["neg"])
+    for _ in range(12):
+        row.step()
+        par.step()
+        ba, bb = row.batch(), par.batch()
+        for k in ("pos_rows", "neg_rows", "pd", "nd", "rho", "kappa"):
+            assert np.array_equal(ba[k], bb[k]), k
+    assert np.array_equal(row.dfavg(), par.dfavg())
+    Wa, Wb = row.W(), par.W()
+    assert Wa.shape == Wb.shape and np.array_equal(Wa, Wb)
+    assert row.validate() == par.validate()
+    assert row.stats() == par.stats()
+    ids = np.arange(0, N, 7, dtype=np.int32)
+    assert np.array_equal(row.project_sqdist(ids, Wa), par.project_sqdist(ids, Wa))
+    row.close()
+    par.close()
+
+
+def test_pair_mode_against_oracle(dlco, ref):
+    """Pair mode teacher-forced against the oracle run on the materialised differences."""
+    N, F, B, P = 3000, 128, 32, 900
+    desc, pairs, D, L = _pair_case(N, F, P, seed=9)
+    mu, gamma = 0.004, 0.5
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_pairs(desc, pairs)
+    checked = 0
+    for s in range(8):
+        before = tr.state()
+        tr.step()
+        after = tr.state()
+        ctx.set_state(s, before["dfavg"], before["W"] if s else None)
+        ctx.step()
+        b = ctx.batch()
+        pr, nr = tr.batch_ids()
+        assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+        pd, nd = tr.batch_dists()
+        scale = max(pd.max(), nd.max(), 1e-30)
+        assert np.abs(b["pd"] - pd).max() <= TOL_DIST * scale and np.abs(b["nd"] - nd).max() <= TOL_DIST * scale
+        rho, kap = ref.viol_counts(pd, nd)
+        if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
+            assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
+            assert relmax(ctx.A(), after["A"]) <= TOL_A
+            checked += 1
+    assert checked >= 5
+    ctx.close()
+    tr.close()
