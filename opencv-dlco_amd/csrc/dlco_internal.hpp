@@ -189,19 +189,19 @@ void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, fl
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
                  hipStream_t s);
 size_t jacobi_work_floats(int n);
-// CholQR building blocks for panels of <= 64 rows: Cholesky of the panel's Gram matrix with
-// dead-row detection, and the forward substitution Q = L^-1 Z (in place allowed).
-void chol_factor64(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl, int *dead, hipStream_t s);
-void trsm_rows64(const float *L, long ldl, const int *dead, int m, const float *Z, float *Q, long ld, int F, hipStream_t s);
+// CholQR building block for panels of <= 128 rows: factors the panel's Gram matrix M = L L^T
+// (only its lower triangle is read) and returns Linv = L^-1 [n][ldl] (lower triangular, upper
+// part zero), so that the orthonormal rows are the plain product Linv * Z.  A row whose pivot
+// falls below rel_thresh * M_jj lies in the span of the rows before it: dead[j] = 1 and row j of
+// Linv is zero.
+constexpr int CHOL_INV_MAX_N = 128;
+void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s);
 // row norms of (Y - theta_i X) and of X
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
 void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);
 // y = H x style GEMV on a symmetric matrix (memory-bound), used by the spectral-bound estimator
 void symv(const float *H, long ld, int F, const float *x, float *y, hipStream_t s);
-// whitening coefficient matrix Cw[n][k] = U[:, keep] * lam^-1/2 for eigenvalues above thresh*lam_max; returns k on host
-void build_whitener(const float *evals, const float *V, long ldv, int n, float rel_thresh, float *Cw, long ldcw,
-                    int *k_out_dev, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // ROC statistics on device (kernels_stats.hip) — src/misc.cpp:297-332

@@ -28,7 +28,8 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     srcrow_.alloc(cap_ + 8);
     jwork_.alloc(jacobi_work_floats(cap_));
     ibuf_.alloc(8);
-    dead_.alloc(64);
+    dead_.alloc(CHOL_INV_MAX_N);
+    if (const char *e = std::getenv("DLCO_PANEL_AMP")) panel_amp_ = std::max(1.0, std::atof(e));
     // filter products run on the bf16 matrix cores with split operands unless DLCO_FP32_FILTER is set
     bf16_filter_ = (F_ % 512 == 0) && std::getenv("DLCO_FP32_FILTER") == nullptr;
     if (bf16_filter_) {
@@ -157,27 +158,6 @@ void EigTracker::rotate(const float *C, long ldc, int k_in, int k_out, const flo
     gemm_f32(g, s_);
 }
 
-// One whitening pass dst = Lambda^-1/2 U^T src from the eigendecomposition of the Gram
-// matrix; rank-revealing (directions below 1e-6 of the largest Gram eigenvalue are dropped).
-int EigTracker::whiten(const float *src, int k, float *dst, bool *well_conditioned)
-{
-    gram(src, src, k, Tm_.p);
-    if (prof_) prof_->begin(PROF_JACOBI);
-    jacobi_eigh(Tm_.p, cap_, k, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
-    if (prof_) prof_->end(PROF_JACOBI);
-    build_whitener(evals_.p, Vm_.p, cap_, k, 1e-6f, Cw_.p, cap_, ibuf_.p, s_);
-    int *hi = reinterpret_cast<int *>(pin_);
-    DLCO_HIP(hipMemcpyAsync(hi, ibuf_.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s_));
-    DLCO_HIP(hipMemcpyAsync(pin_ + 8, evals_.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, s_));
-    DLCO_HIP(hipStreamSynchronize(s_));
-    const int kept = hi[0];
-    st_.jacobi_sweeps += hi[1];
-    if (kept < 1) { if (well_conditioned) *well_conditioned = true; return 0; }
-    if (well_conditioned) *well_conditioned = pin_[8 + kept - 1] > 0.25f * pin_[8];
-    rotate(Cw_.p, cap_, k, kept, src, dst);
-    return kept;
-}
-
 // T[xrows][yrows] (ld cap_) = X * Y^T
 void EigTracker::gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T)
 {
@@ -207,27 +187,23 @@ void EigTracker::project_out(float *Wp, int np, const float *Q, int kept)
     gemm_f32(g, s_);
 }
 
-// Orthonormalise the rows of Z (clobbered) into `out`; returns the kept row count.
-// Block Gram-Schmidt over panels of 32 rows: a panel is projected (twice) against the rows
-// already accepted, renormalised, then whitened by the eigendecomposition of its own Gram
-// matrix.  The rows arrive ordered by Ritz value, i.e. by how strongly the filter amplified
-// them, so every panel is internally well scaled even when the whole block spans a dynamic
-// range that a one-shot fp32 Gram matrix could not resolve.
-int EigTracker::orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends)
+// Orthonormalise the rows of Z in place (`scratch` is a second [rows][F] buffer); returns rows.
+// Block Gram-Schmidt over panels of at most 128 rows: a panel is projected (twice) against the
+// rows already accepted and renormalised, then CholQR2: Gram matrix -> L^-1 on one workgroup
+// -> rows = L^-1 * rows as a GEMM, twice (Z -> scratch -> Z).  The rows arrive ordered by Ritz
+// value, i.e. by how strongly the filter amplified them; the caller cuts the panels so that
+// rows of different provenance or of very different amplification never share one.  Nothing
+// here synchronises with the host and no row is dropped (dependent rows become zero rows).
+int EigTracker::orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends)
 {
-    (void)out;   // in place: no row is ever dropped here (dependent rows become zero rows)
     row_normalize(Z, F_, rows, F_, s_);
-    // panel_ends: ascending row indices, last == rows.  Panels never mix rows of different
-    // provenance or of very different filter amplification (the caller decides the cuts).
-    // Per panel: project against the rows above (twice), renormalise, CholQR2 (Gram -> Cholesky
-    // -> forward substitution, twice).  Nothing here synchronises with the host.
     size_t pi = 0;
     for (int p0 = 0; p0 < rows;) {
         while (pi < panel_ends.size() && panel_ends[pi] <= p0) pi++;
         int pend = pi < panel_ends.size() ? std::min(rows, panel_ends[pi]) : rows;
-        if (pend - p0 > 64) pend = p0 + 64;
+        if (pend - p0 > CHOL_INV_MAX_N) pend = p0 + CHOL_INV_MAX_N;
         const int np = pend - p0;
-        float *Wp = Z + (size_t)p0 * F_;
+        float *Wp = Z + (size_t)p0 * F_, *Sp = scratch + (size_t)p0 * F_;
         if (p0 > 0) {
             for (int pass = 0; pass < 2; pass++) {
                 project_out(Wp, np, Z, p0);
@@ -236,9 +212,16 @@ int EigTracker::orthonormalize(float *Z, int rows, float *out, const std::vector
             }
         }
         for (int pass = 0; pass < 2; pass++) {
-            gram(Wp, Wp, np, Tm_.p);
-            chol_factor64(Tm_.p, cap_, np, 1e-5f, Vm_.p, cap_, dead_.p, s_);
-            trsm_rows64(Vm_.p, cap_, dead_.p, np, Wp, Wp, F_, F_, s_);
+            const float *src = pass == 0 ? Wp : Sp;
+            float *dst = pass == 0 ? Sp : Wp;
+            gram(src, src, np, Tm_.p);
+            chol_inverse128(Tm_.p, cap_, np, 1e-5f, Vm_.p, cap_, dead_.p, s_);
+            GemmArgs g;                                           // dst = Linv * src
+            g.M = np; g.N = F_; g.K = np;
+            g.A.p = Vm_.p; g.A.ld = cap_; g.A.kmajor = false;
+            g.B.p = src; g.B.ld = F_; g.B.kmajor = true;
+            g.C = dst; g.ldc = F_;
+            gemm_f32(g, s_);
         }
         p0 = pend;
     }
@@ -348,22 +331,25 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                 prev = cur; cur = nxt;
             }
             Z = cur;
-            // panels: at most 32 rows, predicted amplification T_d(x_j) within a factor 30 inside a panel
+            // panels: at most 128 rows, predicted amplification T_d(x_j) within panel_amp_ inside a
+            // panel.  A Ritz row carries the directions above it only at the level of its own
+            // residual, so after the filter it is at worst (residual level x amplification ratio)
+            // parallel to them: CholQR2 resolves that as long as the product stays below ~1e2.
             int start = 0;
             double amp0 = 0.0;
             for (int j = 0; j < n_ritz; j++) {
                 const double x = std::max(1.0, (double)(h_theta_[j] - c0) / e0);
                 const double amp = std::cosh((double)d * std::acosh(x));
                 if (j == start) amp0 = amp;
-                else if (j - start >= 64 || amp0 > 100.0 * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
+                else if (j - start >= CHOL_INV_MAX_N || amp0 > panel_amp_ * amp) { panel_ends.push_back(j); start = j; amp0 = amp; }
             }
             if (n_ritz < m_) panel_ends.push_back(n_ritz);
         }
-        for (int j = (panel_ends.empty() ? 0 : panel_ends.back()) + 64; j < m_; j += 64) panel_ends.push_back(j);
+        for (int j = n_ritz + 64; j < m_; j += 64) panel_ends.push_back(j);   // rows without a Ritz value: panels of 64
         panel_ends.push_back(m_);
         // ---- orthonormalise, Rayleigh-Ritz -------------------------------------------------------
         float *Qo = Z;
-        orthonormalize(Z, m_, nullptr, panel_ends);                  // in place
+        orthonormalize(Z, m_, pick({Z}), panel_ends);                // in place
         float *Yb = pick({Qo});
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f, false);     // Yb = Qo * H, exact fp32
         gram(Yb, Qo, m_, Tm_.p);

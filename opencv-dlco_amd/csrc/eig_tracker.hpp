@@ -49,8 +49,7 @@ private:
     void gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T);
     void project_out(float *Wp, int np, const float *Q, int kept);
     void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out);
-    int whiten(const float *src, int k, float *dst, bool *well_conditioned);
-    int orthonormalize(float *Z, int rows, float *out, const std::vector<int> &panel_ends);   // returns kept rows
+    int orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends);
     int drop_dead_rows();
     void refresh_lower_bound(const float *G, int iters, float theta_top);
     void append_random(float *Q, int have, int add);
@@ -68,6 +67,7 @@ private:
     uint64_t rng_ = 0x243F6A8885A308D3ULL;
     float last_crit_ = 0.f;
     int deg0_ = 4;                   // filter degree of the first pass of a step (adapted)
+    double panel_amp_ = 1e4;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
 
     DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F

@@ -1,44 +1,18 @@
-// kernels_eig.hip — small dense symmetric eigenproblems and the vector kernels of the
-// subspace tracker (E1/E2 of the pj-learn step, src/pj-learn.cpp:434-490), for gfx950.
-//
-// jacobi_eigh: one-sided (Hestenes) Jacobi on ONE workgroup of 16 waves.  The input is
-// shifted to be positive definite (T + sigma*I, sigma from a Gershgorin bound) so that the
-// singular vectors the one-sided method finds are the eigenvectors; each wave owns one
-// column pair at a time, columns live in LDS (n <= 128) or in an L2-resident workspace.
+// kernels_eig.hip — vector kernels and the CholQR building block of the subspace tracker
+// (E1/E2 of the pj-learn step, src/pj-learn.cpp:434-490), for gfx950.  The Rayleigh-Ritz
+// eigensolver itself is in kernels_jacobi.hip.
 #include "dlco_internal.hpp"
 
 namespace dlco {
 
 namespace {
 
-constexpr int JT = 1024;          // threads of the Jacobi workgroup
-constexpr int JW = JT / 64;       // waves
-constexpr int JACOBI_LDS_MAX_N = 128;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wsum(float v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// sum over a 16-lane DPP row, result in every lane of the row
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);    // row_half_mirror
-    v += dpp_f<0x140>(v);    // row_mirror
-    return v;
-}
-__device__ __forceinline__ float wmax(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -88,111 +62,137 @@ __global__ __launch_bounds__(256) void symv_kernel(const float *H, long ld, int 
     if (lane == 0) y[row] = s;
 }
 
-__global__ __launch_bounds__(256) void whitener_kernel(const float *evals, const float *V, long ldv, int n,
-                                                       float rel_thresh, float *Cw, long ldcw, int *k_out)
+// CholQR building block: Gram matrix M (n <= 128, lower triangle read) -> Linv = L^-1 with
+// M = L L^T, on one workgroup of 16 waves.
+//
+// Right-looking elimination without pivoting on the augmented matrix [M | I]: step j subtracts
+// (A_ij / A_jj) * row j from every row i > j.  The left half turns into the Schur complements
+// (pivot d_j = A_jj at step j), the right half into U^-1 of M = U D U^T, and L^-1 = D^-1/2 U^-1.
+// Thread (i, g) keeps 32 consecutive entries of row i of the 256-wide augmented matrix in
+// registers (g < 4: columns of M, g >= 4: columns of I); a wave is 64 rows of one column group,
+// so groups that a step cannot touch (M columns <= j, U^-1 columns > j) and rows <= j retire as
+// whole waves.  Pivot row and pivot column of the next step travel through double-buffered
+// LDS vectors: one barrier per step.  A row whose pivot drops below rel_thresh * M_jj lies (to
+// fp32 accuracy) in the span of the rows before it: it is marked dead, eliminated from nothing,
+// and its row of Linv is zero.
+constexpr int CI_T = 1024;
+
+__global__ __launch_bounds__(CI_T) void chol_inv_kernel(const float *M, long ldm, int n, float rel_thresh, float *Linv,
+                                                       long ldl, int *dead)
 {
-    __shared__ int kk;
-    if (threadIdx.x == 0) {
-        const float lmax = evals[0];
-        int k = 0;
-        while (k < n && evals[k] > rel_thresh * lmax && evals[k] > 0.f) k++;
-        kk = k;
-        *k_out = k;
+    __shared__ __attribute__((aligned(16))) float rowbuf[2][256];
+    __shared__ float colbuf[2][128];
+    __shared__ float diag0[128], dpiv[128];
+    __shared__ int deadf[128];
+    const int t = threadIdx.x, i = t & 127, g = t >> 7;
+    const bool is_x = g >= 4;
+    const int c0 = (g & 3) * 32;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) {
+        const int k = c0 + c;
+        if (is_x) v[c] = (i == k) ? 1.f : 0.f;
+        else if (i < n && k < n) v[c] = M[(long)max(i, k) * ldm + min(i, k)];
+        else v[c] = (i == k) ? 1.f : 0.f;
+    }
+    if (t < 128) diag0[t] = t < n ? M[(long)t * ldm + t] : 1.f;
+    if (i == 0) {
+#pragma unroll
+        for (int c = 0; c < 32; c++) rowbuf[0][g * 32 + c] = v[c];
+    }
+    if (g == 0) colbuf[0][i] = v[0];
+    // Fast path (second pass of CholQR2): M = I + E with |E|_F <= 1e-3.  Then M^-1/2 = I - E/2 up
+    // to 3/8 |E|^2 <= 4e-7, the symmetric orthogonaliser replaces the triangular one and the n
+    // sequential elimination steps are skipped.  (Padding entries hold the identity: E = 0 there.)
+    {
+        float e2 = 0.f;
+        if (!is_x) {
+#pragma unroll
+            for (int c = 0; c < 32; c++) { const float e = v[c] - ((i == c0 + c) ? 1.f : 0.f); e2 += e * e; }
+        }
+        e2 = wsum(e2);
+        if ((t & 63) == 0) dpiv[t >> 6] = e2;
     }
     __syncthreads();
-    const int k = kk;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-        const int i = e / n, j = e % n;
-        Cw[(long)i * ldcw + j] = (j < k) ? V[(long)i * ldv + j] * rsqrtf(evals[j]) : 0.f;
-    }
-}
-
-// Left-looking Cholesky of a Gram matrix M (n <= 64) on one wave: lane i owns row i.
-// A row whose pivot drops below rel_thresh * M_jj lies (to fp32 accuracy) in the span of the
-// rows before it: it is marked dead (L_jj = 1, rest of the column 0) and later zeroed.
-__device__ __forceinline__ float lane_bcast(float v, int src_lane)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
-
-// Lane i keeps row i of M and of L in registers (both loops fully unrolled, so every register
-// index is static); L_jk of the pivot row reaches the other lanes through v_readlane.
-__global__ __launch_bounds__(64) void chol64_kernel(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl,
-                                                   int *dead)
-{
-    const int i = threadIdx.x;
-    float Mr[64], Lr[64];
+    {
+        float tot = 0.f;
+        for (int w = 0; w < CI_T / 64; w++) tot += dpiv[w];
+        __syncthreads();                                     // dpiv is reused by the elimination below
+        if (tot <= 1e-6f) {                                   // workgroup-uniform (false for NaN)
+            if (!is_x && i < n) {
 #pragma unroll
-    for (int k = 0; k < 64; k++) {
-        Mr[k] = (i < n && k <= i && k < n) ? M[(long)i * ldm + k] : 0.f;     // lower triangle of the Gram matrix
-        Lr[k] = 0.f;
-    }
-    float diag = 1.f;
-#pragma unroll
-    for (int k = 0; k < 64; k++) diag = (k == i) ? Mr[k] : diag;
-#pragma unroll
-    for (int j = 0; j < 64; j++) {
-        if (j < n) {                                                           // wave-uniform
-            float s = (i >= j) ? Mr[j] : 0.f;
-#pragma unroll
-            for (int k = 0; k < j; k++) s -= Lr[k] * lane_bcast(Lr[k], j);
-            const float d = lane_bcast(s, j);
-            const float mjj = lane_bcast(diag, j);
-            const bool is_dead = !(d > rel_thresh * mjj) || !(mjj > 0.f);
-            float v;
-            if (is_dead) v = (i == j) ? 1.f : 0.f;
-            else v = (i == j) ? sqrtf(d) : s * rsqrtf(d);
-            Lr[j] = (i >= j && i < n) ? v : 0.f;
-            if (i == j) dead[j] = is_dead ? 1 : 0;
+                for (int c = 0; c < 32; c++) {
+                    const int k = c0 + c;
+                    if (k < n) Linv[(long)i * ldl + k] = ((i == k) ? 1.5f : 0.f) - 0.5f * v[c];
+                }
+            }
+            if (t < n) dead[t] = 0;
+            return;
         }
     }
-    if (i < n) {
-#pragma unroll
-        for (int k = 0; k < 64; k++)
-            if (k <= i) L[(long)i * ldl + k] = Lr[k];
-    }
-}
 
-// Q = L^-1 Z for a panel of m <= 64 rows (forward substitution); thread f owns column f, so the
-// whole solve is independent per column and coalesced.  Dead rows become zero.  In place is fine.
-__global__ __launch_bounds__(256) void trsm64_kernel(const float *L, long ldl, const int *dead, int m, const float *Z,
-                                                    float *Q, long ld, int F)
-{
-    // the solved rows of this column stay in registers (loops fully unrolled: static indices);
-    // the coefficients L_ij are wave-uniform and come through the scalar cache
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= F) return;
-    float q[64];
+    // the step loop stays rolled: the body is executed once per step, so an unrolled copy of it
+    // would run entirely out of cold instruction-cache lines
+#pragma unroll 1
+    for (int j = 0; j < n; j++) {
+        const int buf = j & 1;
+        const float piv = rowbuf[buf][j];
+        const float d0 = diag0[j];
+        const bool is_dead = !(piv > rel_thresh * d0) || !(d0 > 0.f);
+        if (t == 0) { dpiv[j] = piv; deadf[j] = is_dead ? 1 : 0; }
+        const bool grp_active = is_x ? (c0 <= j) : (c0 + 31 > j);            // wave-uniform
+        if (!is_dead && grp_active && i > j && i < n) {
+            const float f = colbuf[buf][i] / piv;
+            const f32x4 *rp = reinterpret_cast<const f32x4 *>(&rowbuf[buf][g * 32]);
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        if (i < m) {                                                          // wave-uniform
-            float acc = Z[(long)i * ld + f];
+            for (int q = 0; q < 8; q++) {
+                const f32x4 r = rp[q];
+                v[4 * q + 0] -= f * r[0];
+                v[4 * q + 1] -= f * r[1];
+                v[4 * q + 2] -= f * r[2];
+                v[4 * q + 3] -= f * r[3];
+            }
+        }
+        if (j + 1 < n) {                                                      // publish pivot row / column of step j+1
+            if (i == j + 1) {
+                f32x4 *wp = reinterpret_cast<f32x4 *>(&rowbuf[buf ^ 1][g * 32]);
 #pragma unroll
-            for (int j = 0; j < i; j++) acc -= L[(long)i * ldl + j] * q[j];
-            q[i] = dead[i] ? 0.f : acc / L[(long)i * ldl + i];
-            Q[(long)i * ld + f] = q[i];
-        } else {
-            q[i] = 0.f;
+                for (int q = 0; q < 8; q++) {
+                    f32x4 r = {v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                    wp[q] = r;
+                }
+            }
+            if (g == ((j + 1) >> 5)) {                                        // the two waves that own column j+1 of M
+                const int cn = (j + 1) & 31;
+                float cv = v[0];
+#pragma unroll
+                for (int c = 1; c < 32; c++) cv = (c == cn) ? v[c] : cv;     // register select, no dynamic indexing
+                colbuf[buf ^ 1][i] = cv;
+            }
+        }
+        __syncthreads();
+    }
+    // Linv = D^-1/2 U^-1 (lower triangular); dead rows and the padding are zero
+    if (is_x && i < n) {
+        const bool dd = deadf[i] != 0;
+        const float sc = dd ? 0.f : rsqrtf(dpiv[i]);
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int k = c0 + c;
+            if (k < n) Linv[(long)i * ldl + k] = (k <= i) ? v[c] * sc : 0.f;
         }
     }
+    if (t < n) dead[t] = deadf[t];
 }
 
 }  // namespace
 
-void chol_factor64(const float *M, long ldm, int n, float rel_thresh, float *L, long ldl, int *dead, hipStream_t s)
+void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
 {
-    DLCO_CHECK(n >= 1 && n <= 64, -2, "chol_factor64: n out of range");
-    hipLaunchKernelGGL(chol64_kernel, dim3(1), dim3(64), 0, s, M, ldm, n, rel_thresh, L, ldl, dead);
+    DLCO_CHECK(n >= 1 && n <= CHOL_INV_MAX_N, -2, "chol_inverse128: n out of range");
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(CI_T), 0, s, M, ldm, n, rel_thresh, Linv, ldl, dead);
     DLCO_HIP(hipGetLastError());
 }
-
-void trsm_rows64(const float *L, long ldl, const int *dead, int m, const float *Z, float *Q, long ld, int F, hipStream_t s)
-{
-    DLCO_CHECK(m >= 1 && m <= 64, -2, "trsm_rows64: m out of range");
-    hipLaunchKernelGGL(trsm64_kernel, dim3((F + 255) / 256), dim3(256), 0, s, L, ldl, dead, m, Z, Q, ld, F);
-    DLCO_HIP(hipGetLastError());
-}
-
 
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s)
@@ -212,13 +212,6 @@ void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_nor
 void symv(const float *H, long ld, int F, const float *x, float *y, hipStream_t s)
 {
     hipLaunchKernelGGL(symv_kernel, dim3((F + 3) / 4), dim3(256), 0, s, H, ld, F, x, y);
-    DLCO_HIP(hipGetLastError());
-}
-
-void build_whitener(const float *evals, const float *V, long ldv, int n, float rel_thresh, float *Cw, long ldcw,
-                    int *k_out_dev, hipStream_t s)
-{
-    hipLaunchKernelGGL(whitener_kernel, dim3(1), dim3(256), 0, s, evals, V, ldv, n, rel_thresh, Cw, ldcw, k_out_dev);
     DLCO_HIP(hipGetLastError());
 }
 
