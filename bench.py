@@ -93,6 +93,11 @@ def main():
     ap.add_argument("--latent", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="developer check: run the N > 1 code path (process group, trainer, callbacks) with one rank")
+    ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default="shard",
+                    help="N > 1: column-sharded dual average (all-gathers of a few MB) or replicated dual "
+                         "average with an F x F all-reduce per step")
     ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
     ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
     args = ap.parse_args()
@@ -111,21 +116,35 @@ def main():
     B = Bl * world
 
     trainer = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["DLCO_FORCE_SHARD"] = "1"
+    # RCCL prints a version banner on stdout when a communicator is created: keep fd 1 clean so
+    # that the only thing ever written to the real stdout is the one JSON line of rank 0
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ddist = importlib.import_module("opencv-dlco_amd.dist")
+    shard = use_dist and args.dp_mode == "shard" and F % (128 * world) == 0
     ctx = dlco.Context(F, N, B=B, mu=args.mu, gamma=args.gamma, device=local_rank, rank=rank, world=world,
-                       eig_guard=args.guard, eig_tol=args.eig_tol)
+                       eig_guard=args.guard, eig_tol=args.eig_tol, shard=1 if shard else 0)
     dev_name, _, _ = ctx.device_name()
     U = make_U(F, args.latent, 2215 + 1)
     ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)        # identical bytes on every rank (dataset replicated)
-    if world > 1:
-        engine = ddist.HipEngine(dlco, ctx, torch.device("cuda", local_rank))
-        trainer = ddist.DataParallelTrainer(engine)
+    if use_dist:
+        if shard:
+            trainer = ddist.ShardedTrainer(dlco, ctx, torch.device("cuda", local_rank))
+        else:
+            trainer = ddist.DataParallelTrainer(ddist.HipEngine(dlco, ctx, torch.device("cuda", local_rank)))
 
     def run(n):
         if trainer is None:
@@ -135,7 +154,7 @@ def main():
 
     def barrier():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -149,7 +168,7 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -169,6 +188,8 @@ def main():
     # src/pj-learn.cpp:378), so the per-launch figure uses the measured mean row count K <= 2*Bl.
     k_mean = (cn1["active_rows"] - cn0["active_rows"]) / max(cn1["steps"] - cn0["steps"], 1)
     flops_launch = 2.0 * k_mean * F * F
+    if shard:                      # the rank's launch covers its F x F/world column slab over the whole global batch
+        flops_launch /= world
     ach = flops_launch / (ms_syrk / max(n_syrk, 1) * 1e-3) / 1e12 if n_syrk else None
     out = {
         "metric": "pj-learn patch-pairs/sec",
@@ -187,7 +208,9 @@ def main():
             "workload": "pj-learn Liberty-shaped %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
                         % (N, F, Bl, Bl, B, B, args.mu, args.gamma, rank_now, args.warmup + args.steps),
             "device": dev_name,
-            "parallelism": "dp%d (replicated data, batch slots sharded, all-gather dists + all-reduce gradient)" % world,
+            "parallelism": ("dp%d (replicated data, batch slots sharded; dual average sharded by columns: all-gather of the "
+                            "2B distances and of the tracker products' column slabs, no F x F exchange)" % world) if shard else
+                           ("dp%d (replicated data, batch slots sharded, all-gather dists + all-reduce gradient)" % world),
             "combinations_per_s": float(B) * B * args.steps / dt,
         },
         "roofline": {
@@ -197,13 +220,13 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
-            "traffic": pmc_traffic(F, Bl),
+            "traffic": pmc_traffic(F, Bl) if world == 1 else None,
             "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_syrk.json); algorithmic bytes 8*F*F + 4*K*F = %d" % int(8 * F * F + 4 * k_mean * F),
             "avg_launch_ms": ms_syrk / max(n_syrk, 1),
             "launches": n_syrk,
             "algorithmic_flops_per_launch": flops_launch,
             "mean_active_rows_per_launch": k_mean,
-            "executed_flops_per_launch": flops_launch * (F // 128 + 1) / (2.0 * (F // 128)),
+            "executed_flops_per_launch": flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128)),
             "tracker_nonconverged_steps": cn1["nonconverged"] - cn0["nonconverged"],
         },
         "breakdown_ms_per_step": {
@@ -222,9 +245,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ctx, F, Bl, args.mu, args.gamma, args.cpu_rows)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

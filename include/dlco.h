@@ -28,6 +28,7 @@ extern "C" {
 #define DLCO_ERR_HIP      -3   /* HIP runtime error (message has details)  */
 #define DLCO_ERR_NODEVICE -4   /* no usable gfx950 device                  */
 #define DLCO_ERR_NOCONV   -5   /* eigen tracker did not reach its tolerance */
+#define DLCO_ERR_COMM     -6   /* the host's collective callback failed      */
 
 typedef struct dlco_ctx dlco_ctx;
 
@@ -46,7 +47,13 @@ typedef struct dlco_cfg {
     float    eig_tol;    /* subspace tracker tolerance on c*|residual| / max e (default 2e-4) */
     int32_t  eig_guard;  /* guard vectors kept beyond the positive eigenspace (default 32)  */
     int32_t  eig_max_iter; /* filter+Rayleigh-Ritz iterations per step before giving up      */
-    int32_t  reserved[8];
+    int32_t  shard;      /* world > 1 only.  0: every rank keeps the whole dual average, the F x F
+                          * partial gradients are all-reduced (dlco_step_begin/grad/finish).
+                          * 1: the dual average is sharded by columns, rank g owns columns
+                          * [g*F/world, (g+1)*F/world); no F x F exchange, the step (dlco_step) calls
+                          * the all-gather registered with dlco_set_allgather.  F % (128*world) == 0
+                          * selects the fused kernels.                                            */
+    int32_t  reserved[7];
 } dlco_cfg;
 
 void dlco_cfg_default(dlco_cfg *cfg);
@@ -115,12 +122,26 @@ int dlco_step_finish(dlco_ctx *ctx);
 #define DLCO_BUF_GRAD   2   /* f32 [F*F]: this rank's dLoss partial                    */
 #define DLCO_BUF_DFAVG  3   /* f32 [F*F]: running dual average                         */
 #define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
+#define DLCO_BUF_GATHER 5   /* f32 [world][rows*F/world]: column slabs of a tracker product
+                               (sharded contexts only)                                   */
 /* Device pointer and byte size of an exchange buffer (valid until ctx is destroyed). */
 int dlco_dev_buffer(dlco_ctx *ctx, int32_t which, void **dev_ptr, size_t *bytes);
-/* Makes the context use caller-owned device memory for an exchange buffer (DLCO_BUF_DIST or
- * DLCO_BUF_GRAD), e.g. a tensor the caller's RCCL communicator operates on.  The memory
- * must outlive the context. */
+/* Makes the context use caller-owned device memory for an exchange buffer (DLCO_BUF_DIST,
+ * DLCO_BUF_GRAD or DLCO_BUF_GATHER), e.g. a tensor the caller's RCCL communicator operates
+ * on.  The memory must outlive the context. */
 int dlco_bind_buffer(dlco_ctx *ctx, int32_t which, void *dev_ptr, size_t bytes);
+
+/* Sharded contexts (cfg.shard = 1, world > 1): the collective the step needs, supplied by the
+ * host.  fn(user, which, bytes_per_rank) must all-gather, IN PLACE, the first
+ * world*bytes_per_rank bytes of exchange buffer `which` (DLCO_BUF_DIST or DLCO_BUF_GATHER)
+ * viewed as [world][bytes_per_rank] — the rank's own chunk is already filled — ordered after
+ * the work queued on dlco_stream() and visible to work queued there afterwards (enqueue the
+ * RCCL call on that stream, or synchronise around it).  Return 0 on success.  dlco_step calls
+ * it once for the 2B distances and once per product of the eigen tracker with the dual
+ * average (about six times a step, 4*rows*F/world bytes per rank each); every rank makes the
+ * same sequence of calls.  The reference has no counterpart (single device). */
+typedef int (*dlco_allgather_fn)(void *user, int32_t which, size_t bytes_per_rank);
+int dlco_set_allgather(dlco_ctx *ctx, dlco_allgather_fn fn, void *user);
 /* The HIP stream the context launches on (as void*), so callers can order collectives. */
 int dlco_stream(dlco_ctx *ctx, void **stream);
 int dlco_sync(dlco_ctx *ctx);

@@ -17,8 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdlco.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dlco.h")
 
-OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOCONV = 0, -2, -3, -4, -5
-BUF_DIST, BUF_GRAD, BUF_DFAVG, BUF_W = 1, 2, 3, 4
+OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOCONV, ERR_COMM = 0, -2, -3, -4, -5, -6
+BUF_DIST, BUF_GRAD, BUF_DFAVG, BUF_W, BUF_GATHER = 1, 2, 3, 4, 5
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_size_t)
 
 
 class DlcoError(RuntimeError):
@@ -34,7 +35,8 @@ class Cfg(C.Structure):
         ("seed", C.c_uint64),
         ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
         ("eig_tol", C.c_float), ("eig_guard", C.c_int32), ("eig_max_iter", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("shard", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -91,6 +93,7 @@ def load():
     L.dlco_dev_buffer.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.dlco_bind_buffer.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.dlco_stream.argtypes = [vp, C.POINTER(vp)]
+    L.dlco_set_allgather.argtypes = [vp, ALLGATHER_FN, vp]
     L.dlco_get_batch.argtypes = [vp, i32p, i32p, f32p, f32p, i32p, i32p]
     L.dlco_get_t.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.dlco_get_W.argtypes = [vp, f32p, i32p]
@@ -139,12 +142,12 @@ class Context:
     """One pj-learn trainer on one GPU (thin wrapper over dlco_ctx)."""
 
     def __init__(self, F, N, B=200, mu=0.001, gamma=0.5, seed=2215, device=0, rank=0, world=1,
-                 eig_tol=None, eig_guard=None, eig_max_iter=None):
+                 eig_tol=None, eig_guard=None, eig_max_iter=None, shard=0):
         self.L = load()
         cfg = Cfg()
         self.L.dlco_cfg_default(C.byref(cfg))
         cfg.F, cfg.N, cfg.B, cfg.mu, cfg.gamma, cfg.seed = F, N, B, mu, gamma, seed
-        cfg.device, cfg.rank, cfg.world = device, rank, world
+        cfg.device, cfg.rank, cfg.world, cfg.shard = device, rank, world, shard
         if eig_tol is not None:
             cfg.eig_tol = eig_tol
         if eig_guard is not None:
@@ -243,6 +246,18 @@ class Context:
         p = C.c_void_p()
         self._ck(self.L.dlco_stream(self.h, C.byref(p)))
         return p.value
+
+    def set_allgather(self, fn):
+        """fn(which, bytes_per_rank) -> 0 on success; kept alive by the context (see dlco_set_allgather)."""
+        def tramp(_user, which, nbytes):
+            try:
+                return int(fn(int(which), int(nbytes)) or 0)
+            except Exception:                    # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._ag = ALLGATHER_FN(tramp)
+        self._ck(self.L.dlco_set_allgather(self.h, self._ag, None))
 
     def batch(self):
         B = self.B

@@ -66,6 +66,13 @@ struct dlco_ctx {
 
     // HIP-event timers (gradient SYRK, tracker products, ...)
     Profiler prof;
+
+    // column-sharded dual average (cfg.shard, world > 1): see dlco_set_allgather
+    bool shard = false;
+    ShardComm comm;
+    DevBuf<float> gather_own;
+    dlco_allgather_fn ag_fn = nullptr;
+    void *ag_user = nullptr;
 };
 
 namespace {
@@ -90,6 +97,14 @@ int guarded(const dlco_ctx *ctx, Fn &&fn)
 }
 
 void sync(dlco_ctx *c) { DLCO_HIP(hipStreamSynchronize(c->stream)); }
+
+// in-place all-gather of one of the exchange buffers through the host's collective (RCCL)
+void allgather(dlco_ctx *c, int32_t buffer_id, size_t bytes_per_rank)
+{
+    DLCO_CHECK(c->ag_fn != nullptr, DLCO_ERR_INVALID, "sharded step: no all-gather callback (dlco_set_allgather)");
+    const int rc = c->ag_fn(c->ag_user, buffer_id, bytes_per_rank);
+    if (rc != 0) throw Error(DLCO_ERR_COMM, "all-gather callback failed with code " + std::to_string(rc));
+}
 
 void h2d(dlco_ctx *c, void *dst, const void *src, size_t bytes)
 {
@@ -191,9 +206,11 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
     const int kpad = (kmax + 31) & ~31;                 // the lists are zero padded up to here
     const RowRef rr = rows_of(c, ids, 0, kpad);
     // fused, symmetric, branch-free kernel when the shape allows it (F a multiple of 128)
-    if (c->F % 128 == 0 && (reinterpret_cast<uintptr_t>(c->dists) & 15) == 0) {
+    if (c->F % 128 == 0 && (reinterpret_cast<uintptr_t>(c->dists) & 15) == 0 &&
+        (!c->shard || (c->comm.c0 % 128 == 0 && c->comm.cw % 128 == 0))) {
         c->prof.begin(PROF_GRAD_SYRK);
-        const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream);
+        const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream,
+                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;
@@ -205,7 +222,8 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
     g.C = dst; g.ldc = c->F;
     g.alpha = alpha; g.beta = beta;
     g.k_dev = k_dev;
-    g.upper_only = true;
+    g.upper_only = !c->shard;
+    if (c->shard) { g.N = c->comm.cw; g.B.p = c->dists + c->comm.c0; g.C = dst + c->comm.c0; }   // the rank's column slab
     c->prof.begin(PROF_GRAD_SYRK);
     gemm_f32(g, c->stream);
     c->prof.end(PROF_GRAD_SYRK);
@@ -245,6 +263,7 @@ void step_begin(dlco_ctx *c)
 void step_grad(dlco_ctx *c)
 {
     DLCO_CHECK(c->phase == 1, DLCO_ERR_INVALID, "dlco_step_grad: call dlco_step_begin first");
+    DLCO_CHECK(!c->shard, DLCO_ERR_INVALID, "dlco_step_grad: a sharded context steps with dlco_step");
     const int B = c->B, Bl = c->Bl, world = c->cfg.world;
     for (int g = 0; g < world; g++) {
         DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
@@ -265,7 +284,7 @@ void step_grad(dlco_ctx *c)
 void step_finish(dlco_ctx *c)
 {
     DLCO_CHECK(c->phase == 2, DLCO_ERR_INVALID, "dlco_step_finish: call dlco_step_grad first");
-    if (c->cfg.world > 1) {
+    if (c->cfg.world > 1 && !c->shard) {
         float alpha, beta;
         rda_coeffs(c, &alpha, &beta);
         axpby_inplace(c->dfavg.p, c->xgrad, beta, alpha, (size_t)c->F * c->F, c->stream);
@@ -299,6 +318,31 @@ void step_finish(dlco_ctx *c)
     }
     c->t++;
     c->phase = 0;
+}
+
+// One step with the dual average sharded by columns (cfg.shard): the rank projects its batch
+// slots, all-gathers the 2B distances, computes its column slab of the gradient over the WHOLE
+// global batch fused with the dual-average update (no F x F exchange), and runs the replicated
+// tracker whose products with dfAvg all-gather their column slabs.
+void step_sharded(dlco_ctx *c)
+{
+    step_begin(c);
+    allgather(c, DLCO_BUF_DIST, (size_t)2 * c->Bl * sizeof(float));
+    const int B = c->B, Bl = c->Bl, world = c->cfg.world;
+    for (int g = 0; g < world; g++) {
+        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+    viol_counts(c->pd.p, c->nd.p, B, c->rho.p, c->kappa.p, c->stream);
+    build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, 0, B, c->act_ids.p, c->act_w.p, c->k_active.p,
+                      c->stream);
+    float alpha, beta;
+    rda_coeffs(c, &alpha, &beta);
+    grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * B, alpha, beta, c->dfavg.p);
+    c->phase = 2;
+    step_finish(c);
 }
 
 void get_W_host(dlco_ctx *c, float *W_host, int32_t *r)
@@ -414,6 +458,18 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
         c->dscal.alloc(4);
+        // column-sharded dual average (world > 1, or forced for single-rank testing of the path)
+        c->shard = cfg->shard != 0 && (cfg->world > 1 || std::getenv("DLCO_FORCE_SHARD") != nullptr);
+        if (c->shard) {
+            DLCO_CHECK(c->F % (4 * cfg->world) == 0, DLCO_ERR_INVALID, "shard: F must be a multiple of 4*world");
+            c->comm.world = cfg->world; c->comm.rank = cfg->rank;
+            c->comm.cw = c->F / cfg->world; c->comm.c0 = cfg->rank * c->comm.cw;
+            c->comm.gather_floats = (size_t)c->w_cap * c->F;
+            c->gather_own.alloc(c->comm.gather_floats);
+            c->comm.gather = c->gather_own.p;
+            c->comm.allgather = [c](size_t bytes) { allgather(c, DLCO_BUF_GATHER, bytes); };
+            c->eig->set_shard(&c->comm);
+        }
         sync(c);
     });
     if (rc != DLCO_OK) { delete c; return rc; }
@@ -550,7 +606,9 @@ int dlco_step(dlco_ctx *c)
     if (!c) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
-        DLCO_CHECK(c->cfg.world == 1, DLCO_ERR_INVALID, "dlco_step: world > 1 needs the begin/grad/finish protocol");
+        if (c->shard) { step_sharded(c); return; }
+        DLCO_CHECK(c->cfg.world == 1, DLCO_ERR_INVALID,
+                   "dlco_step: world > 1 needs cfg.shard + dlco_set_allgather, or the begin/grad/finish protocol");
         step_begin(c); step_grad(c); step_finish(c);
     });
 }
@@ -573,6 +631,9 @@ int dlco_dev_buffer(dlco_ctx *c, int32_t which, void **dev_ptr, size_t *bytes)
     case DLCO_BUF_GRAD: *dev_ptr = c->xgrad; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_DFAVG: *dev_ptr = c->dfavg.p; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_W: *dev_ptr = c->W.p; *bytes = (size_t)c->r * c->F * sizeof(float); return DLCO_OK;
+    case DLCO_BUF_GATHER:
+        if (!c->shard) return DLCO_ERR_INVALID;
+        *dev_ptr = c->comm.gather; *bytes = c->comm.gather_floats * sizeof(float); return DLCO_OK;
     default: return DLCO_ERR_INVALID;
     }
 }
@@ -588,8 +649,12 @@ int dlco_bind_buffer(dlco_ctx *c, int32_t which, void *dev_ptr, size_t bytes)
         } else if (which == DLCO_BUF_GRAD) {
             DLCO_CHECK(bytes >= (size_t)c->F * c->F * sizeof(float), DLCO_ERR_INVALID, "dlco_bind_buffer: GRAD buffer too small");
             c->xgrad = static_cast<float *>(dev_ptr);
+        } else if (which == DLCO_BUF_GATHER) {
+            DLCO_CHECK(c->shard, DLCO_ERR_INVALID, "dlco_bind_buffer: GATHER exists only in a sharded context");
+            DLCO_CHECK(bytes >= c->comm.gather_floats * sizeof(float), DLCO_ERR_INVALID, "dlco_bind_buffer: GATHER buffer too small");
+            c->comm.gather = static_cast<float *>(dev_ptr);
         } else {
-            throw Error(DLCO_ERR_INVALID, "dlco_bind_buffer: only DLCO_BUF_DIST and DLCO_BUF_GRAD can be bound");
+            throw Error(DLCO_ERR_INVALID, "dlco_bind_buffer: only DLCO_BUF_DIST, DLCO_BUF_GRAD and DLCO_BUF_GATHER can be bound");
         }
     });
 }
@@ -598,6 +663,14 @@ int dlco_stream(dlco_ctx *c, void **stream)
 {
     if (!c || !stream) return DLCO_ERR_INVALID;
     *stream = (void *)c->stream;
+    return DLCO_OK;
+}
+
+int dlco_set_allgather(dlco_ctx *c, dlco_allgather_fn fn, void *user)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    c->ag_fn = fn;
+    c->ag_user = user;
     return DLCO_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -135,16 +136,21 @@ void gemm_f32(const GemmArgs &a, hipStream_t s);
 // fp32 accumulation; ~1e-5 relative error): kernels_bf16x2.hip.  plane_hi/lo are workspaces of
 // bf16x2_plane_bytes(M, K) bytes each.  Returns false for unsupported shapes.
 size_t bf16x2_plane_bytes(int M, int K);
-size_t bf16x2_slab_floats(int M, int N);
+size_t bf16x2_slab_floats(int M, int N, int ksplit = 0);
+// ksplit: number of K slices (grid y, default 4); K must be a multiple of 128 * ksplit.  A column slab of G
+// (N < K) takes ksplit = 4 * K / N so that the launch still fills the chip.
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
-                           float *slab, hipStream_t s);
+                           float *slab, hipStream_t s, int ksplit = 0);
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).
 // ids2 != nullptr (pair mode): row k is D[ids[k]] - D[ids2[k]], formed on the fly.
+// slab_cols > 0 (dual average sharded over GPUs): only the columns [slab_col0, slab_col0 + slab_cols)
+// of C are computed and stored (all rows, no mirror); both must be multiples of 128.
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
-                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s);
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
+                  int slab_cols = 0);
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,
@@ -176,6 +182,21 @@ void scale_rows(float *dst, long ldd, const float *src, long lds, const float *s
 void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb, int32_t *out_a, int32_t *out_b,
                    hipStream_t s);
 void fill_f32(float *p, float v, size_t n, hipStream_t s);
+
+// Column-sharded dual average (one slab of F/world columns per rank): what the tracker and the
+// step need to know about the decomposition and how they reach the other ranks.  `allgather`
+// performs an in-place all-gather of `gather` viewed as [world][bytes_per_rank] (the rank's own
+// chunk is filled by the caller), stream-ordered after the work already queued on the library
+// stream; it throws on failure.
+struct ShardComm {
+    int world = 1, rank = 0;
+    int c0 = 0, cw = 0;                  // this rank's columns [c0, c0 + cw)
+    float *gather = nullptr;             // exchange buffer, >= gather_floats
+    size_t gather_floats = 0;
+    std::function<void(size_t bytes_per_rank)> allgather;
+};
+void pack_cols(float *dst, const float *src, long ld, int c0, int cw, int rows, hipStream_t s);
+void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int world, hipStream_t s);
 
 // synthetic stand-in for a *-unproj.h5 generated in HBM (bench): d = U^T z + eps, clipped
 void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,

@@ -100,6 +100,39 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
                          const float *E2, float b2, bool approx)
 {
     st_.product_rows += rows;
+    if (shard_) {
+        // the rank's column slab out[:, c0:c0+cw] = alpha * X * G[:, c0:c0+cw] + ..., then all-gather
+        const int c0 = shard_->c0, cw = shard_->cw, world = shard_->world;
+        DLCO_CHECK((size_t)world * rows * cw <= shard_->gather_floats, -2, "eig tracker: exchange buffer too small");
+        const float *E1s = E1 ? E1 + c0 : nullptr, *E2s = E2 ? E2 + c0 : nullptr;
+        if (prof_) prof_->begin(PROF_EIG_PRODUCT);
+        bool done = false;
+        if (approx && bf16_filter_ && rows <= 128) {
+            int ks = 4;                                              // keep ~256 workgroups in flight
+            while (ks < 4 * world && F_ % (128 * ks * 2) == 0 && bf16x2_slab_floats(rows, cw, ks * 2) <= slab_floats_) ks *= 2;
+            done = skinny_product_bf16x2(X, F_, rows, G + c0, F_, cw, F_, alpha, out + c0, F_, E1s, b1, E2s, b2, plane_hi_.p,
+                                         plane_lo_.p, slab_.p, s_, ks);
+        }
+        if (!done) {
+            GemmArgs g;
+            g.M = rows; g.N = cw; g.K = F_;
+            g.A.p = X; g.A.ld = F_; g.A.kmajor = false;
+            g.B.p = G + c0; g.B.ld = F_; g.B.kmajor = true;
+            g.C = out + c0; g.ldc = F_;
+            g.alpha = alpha; g.E1 = E1s; g.b1 = b1; g.E2 = E2s; g.b2 = b2;
+            const long tiles = (long)ceil_div(rows, rows <= 64 ? 64 : 128) * ceil_div(cw, 128);
+            long split = std::max(1L, std::min((long)ceil_div(512, tiles), (long)F_ / 256));
+            split = std::min(split, (long)(slab_floats_ / ((size_t)rows * cw)));
+            g.split_k = (int)std::max(1L, split);
+            g.slab = slab_.p;
+            gemm_f32(g, s_);
+        }
+        if (prof_) prof_->end(PROF_EIG_PRODUCT);
+        pack_cols(shard_->gather + (size_t)shard_->rank * rows * cw, out, F_, c0, cw, rows, s_);
+        shard_->allgather((size_t)rows * cw * sizeof(float));
+        unpack_cols(out, F_, shard_->gather, cw, rows, world, s_);
+        return;
+    }
     if (approx && bf16_filter_ && rows <= 128 && F_ >= 256) {
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         const bool ok = skinny_product_bf16x2(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p,
@@ -264,7 +297,8 @@ void EigTracker::refresh_lower_bound(const float *G, int iters, float theta_top)
     auto run = [&](float shift, int n) -> float {
         float *v = pv_.p, *w = pw_.p;
         for (int i = 0; i < n; i++) {
-            symv(G, F_, F_, v, w, s_);
+            if (shard_) product(v, 1, G, 1.0f, w, nullptr, 0.f, nullptr, 0.f, false);   // v^T G = (G v)^T, G symmetric
+            else symv(G, F_, F_, v, w, s_);
             if (shift != 0.f) axpby_inplace(w, v, 1.0f, shift, F_, s_);
             if (i == n - 1) residual_norms(v, w, F_, scale_.p, 1, F_, res_.p, s_);   // |w|
             row_normalize(w, F_, 1, F_, s_);

@@ -39,6 +39,9 @@ public:
 
     int block_rows() const { return m_; }
     void set_profiler(Profiler *p) { prof_ = p; }
+    // G is sharded by columns over the ranks: every product with G computes the rank's column slab
+    // and all-gathers the rest; everything else of the tracker is replicated (and deterministic).
+    void set_shard(const ShardComm *sc) { shard_ = sc; }
     const EigStats &stats() const { return st_; }
     float last_crit() const { return last_crit_; }
 
@@ -86,6 +89,7 @@ private:
     size_t pin_floats_ = 0;
     EigStats st_;
     Profiler *prof_ = nullptr;
+    const ShardComm *shard_ = nullptr;
 };
 
 }  // namespace dlco

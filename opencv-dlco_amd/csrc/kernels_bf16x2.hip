@@ -27,7 +27,7 @@ namespace {
 
 constexpr int W8 = 8;             // waves per workgroup
 constexpr int T8 = 64 * W8;
-constexpr int KS = 4;             // K quarters (blockIdx.y), summed in order by splitk_reduce_f32
+constexpr int KS = 4;             // default K split (gridDim.y); the slices are summed in order by splitk_reduce_f32
 
 // plane element ((k16 * MT + tile) * 64 + lane) * 8 + j  =  X[tile*32 + (lane&31)][k16*16 + 8*(lane>>5) + j]
 __global__ __launch_bounds__(256) void split_x_kernel(const float *X, long ldx, int M, int MT, int K, bf16x8 *hi, bf16x8 *lo)
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(T8) void skinny_bf16x2_kernel(Bf2Dev g)
     const int ct = wave & 3, kh = wave >> 2;
     const int col = blockIdx.x * 128 + ct * 32 + lc;
     const int nsteps = g.K / 16;
-    const int per = nsteps / (KS * 2);            // host guarantees divisibility
+    const int per = nsteps / ((int)gridDim.y * 2);        // host guarantees divisibility (and per % 4 == 0)
     const int s0 = (blockIdx.y * 2 + kh) * per, s1 = s0 + per;
 
     f32x16 acc[MT];
@@ -92,17 +92,8 @@ __global__ __launch_bounds__(T8) void skinny_bf16x2_kernel(Bf2Dev g)
     // was measured 15 % slower: 32 distinct lines per wave instruction.)
     auto load_g = [&](int s, float (&gv)[8]) {
         const float *p = g.G + ((long)s * 16 + 8 * lh) * g.ldg + col;
-#ifdef DLCO_EXPERIMENT_WIDE_G
-        // timing experiment only (wrong lane mapping): same bytes as 16-byte loads
-        const float *pw = g.G + ((long)s * 16 + 8 * lh) * g.ldg + blockIdx.x * 128 + lc * 4;
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pw + (long)(2 * ct) * g.ldg);
-        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pw + (long)(2 * ct + 1) * g.ldg);
-        for (int j = 0; j < 4; j++) { gv[j] = v0[j]; gv[4 + j] = v1[j]; }
-        (void)p;
-#else
 #pragma unroll
         for (int j = 0; j < 8; j++) gv[j] = p[(long)j * g.ldg];
-#endif
     };
     auto load_a = [&](int s, bf16x8 (&h)[MT], bf16x8 (&l)[MT]) {
 #pragma unroll
@@ -176,15 +167,16 @@ __global__ __launch_bounds__(T8) void skinny_bf16x2_kernel(Bf2Dev g)
 }  // namespace
 
 size_t bf16x2_plane_bytes(int M, int K) { return (size_t)((M + 31) / 32) * 32 * K * sizeof(__bf16); }
-size_t bf16x2_slab_floats(int M, int N) { return (size_t)KS * M * N; }
+size_t bf16x2_slab_floats(int M, int N, int ksplit) { return (size_t)(ksplit > 0 ? ksplit : KS) * M * N; }
 
 // Returns false when the shape is not supported (caller falls back to the fp32 kernel).
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
-                           float *slab, hipStream_t s)
+                           float *slab, hipStream_t s, int ksplit)
 {
     const int mt = (M + 31) / 32;
-    if (M < 1 || mt > 4 || N % 128 != 0 || K % (16 * KS * 2 * 4) != 0) return false;   // 4 steps per loop trip
+    const int ks = ksplit > 0 ? ksplit : KS;
+    if (M < 1 || mt > 4 || N % 128 != 0 || K % (16 * ks * 2 * 4) != 0) return false;   // 4 steps per loop trip
     if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) return false;
     const long total = (long)(K / 16) * mt * 64;
     hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, K,
@@ -193,13 +185,13 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
     g.M = M; g.N = N; g.K = K;
     g.xhi = static_cast<const bf16x8 *>(plane_hi); g.xlo = static_cast<const bf16x8 *>(plane_lo);
     g.G = G; g.ldg = ldg; g.slab = slab;
-    const dim3 grid(N / 128, KS), block(T8);
+    const dim3 grid(N / 128, ks), block(T8);
     if (mt == 1) hipLaunchKernelGGL(skinny_bf16x2_kernel<1>, grid, block, 0, s, g);
     else if (mt == 2) hipLaunchKernelGGL(skinny_bf16x2_kernel<2>, grid, block, 0, s, g);
     else if (mt == 3) hipLaunchKernelGGL(skinny_bf16x2_kernel<3>, grid, block, 0, s, g);
     else hipLaunchKernelGGL(skinny_bf16x2_kernel<4>, grid, block, 0, s, g);
     DLCO_HIP(hipGetLastError());
-    splitk_reduce_f32(slab, KS, M, N, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
+    splitk_reduce_f32(slab, ks, M, N, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
     return true;
 }
 

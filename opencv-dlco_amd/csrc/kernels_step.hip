@@ -184,6 +184,27 @@ __global__ void translate_ids_kernel(const int32_t *ids, int base, int n, const 
     out_b[i] = pb[r];
 }
 
+// column slabs of a [rows][ld] block <-> the [world][rows][cw] exchange layout of the all-gather
+__global__ void pack_cols_kernel(float *dst, const float *src, long ld, int c0, int cw, int rows)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;           // float4 index
+    const int q = cw >> 2;
+    if (e >= (long)rows * q) return;
+    const int i = (int)(e / q), c = (int)(e % q) * 4;
+    *reinterpret_cast<float4 *>(dst + (long)i * cw + c) = *reinterpret_cast<const float4 *>(src + (long)i * ld + c0 + c);
+}
+
+__global__ void unpack_cols_kernel(float *dst, long ld, const float *src, int cw, int rows, int world)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = cw >> 2;
+    if (e >= (long)world * rows * q) return;
+    const int c = (int)(e % q) * 4;
+    const long t = e / q;
+    const int i = (int)(t % rows), g = (int)(t / rows);
+    *reinterpret_cast<float4 *>(dst + (long)i * ld + (long)g * cw + c) = *reinterpret_cast<const float4 *>(src + ((long)g * rows + i) * cw + c);
+}
+
 // ---- synthetic data ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix(uint64_t x)
 {
@@ -288,6 +309,22 @@ void scale_rows(float *dst, long ldd, const float *src, long lds, const float *s
     if (rows <= 0) return;
     hipLaunchKernelGGL(scale_rows_kernel, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, scale, src_rows, src_rows2, rows,
                        cols);
+    DLCO_HIP(hipGetLastError());
+}
+
+void pack_cols(float *dst, const float *src, long ld, int c0, int cw, int rows, hipStream_t s)
+{
+    if (rows <= 0) return;
+    const long n4 = (long)rows * (cw / 4);
+    hipLaunchKernelGGL(pack_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, src, ld, c0, cw, rows);
+    DLCO_HIP(hipGetLastError());
+}
+
+void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int world, hipStream_t s)
+{
+    if (rows <= 0) return;
+    const long n4 = (long)world * rows * (cw / 4);
+    hipLaunchKernelGGL(unpack_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, ld, src, cw, rows, world);
     DLCO_HIP(hipGetLastError());
 }
 

@@ -44,6 +44,7 @@ struct SyrkDev {
     long ldc;
     float alpha, beta;
     int nt;                       // tiles per edge
+    int slab_t0, slab_nt;         // column-slab mode: tile columns [slab_t0, slab_t0 + slab_nt) only
 };
 
 union SyrkLds {
@@ -51,13 +52,16 @@ union SyrkLds {
     float T[TB][TLD];                                          // 66,048 B
 };
 
-template <bool PAIR>
+// SLAB = false: the whole symmetric matrix (upper tiles computed, mirrored).
+// SLAB = true : only the tile columns [slab_t0, slab_t0 + slab_nt) of the matrix, all tile rows,
+//               no mirror — the rank's column slab of a dual average that is sharded over GPUs.
+template <bool PAIR, bool SLAB>
 __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
 
-    // ---- tile assignment: XCD-contiguous chunks over the upper-triangular tile list ---------
-    const int ntiles = g.nt * (g.nt + 1) / 2;
+    // ---- tile assignment: XCD-contiguous chunks over the tile list --------------------------------
+    const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
     const int nxcd = 8;
     const int bid = blockIdx.x;
     int t;
@@ -65,17 +69,18 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;     // bijective remap
     }
-    // row-major enumeration of (bi <= bj): tile t -> (bi, bj)
-    int bi = 0, rem = t;
-    {
-        // solve bi: offset(bi) = bi*nt - bi*(bi-1)/2 <= t
+    int bi = 0, bj = 0;
+    if (SLAB) {
+        bi = t / g.slab_nt;                                   // neighbours share the row panel
+        bj = g.slab_t0 + t % g.slab_nt;
+    } else {
+        // row-major enumeration of (bi <= bj): solve offset(bi) = bi*nt - bi*(bi-1)/2 <= t
         float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
         bi = max(0, min(g.nt - 1, (int)fb));
         while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
         while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
-        rem = t - (bi * g.nt - bi * (bi - 1) / 2);
+        bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
     }
-    const int bj = bi + rem;
     const int i0 = bi * TB, j0 = bj * TB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
                     o[e] = g.alpha * acc[a][b][r] + g.beta * oldv[a][b][r];
                 }
                 const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;       // rows il0 .. il0+3
-                if (!diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+                if (!SLAB && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
 #pragma unroll
                 for (int e = 0; e < 4; e++) lds.T[il0 + e][jl] = o[e];
             }
@@ -215,15 +220,23 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 }  // namespace
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
-                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s)
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
+    const bool slab = slab_cols > 0;
+    if (slab && (slab_col0 % TB != 0 || slab_cols % TB != 0 || slab_col0 + slab_cols > F)) return false;
     SyrkDev g;
     g.D = D; g.ldd = ldd; g.ids = ids; g.ids2 = ids2; g.w = w; g.k_dev = k_dev; g.kmax = kmax; g.F = F;
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
-    const int ntiles = g.nt * (g.nt + 1) / 2;
-    if (ids2) hipLaunchKernelGGL(syrk_rda_kernel<true>, dim3(ntiles), dim3(NTH), 0, s, g);
-    else hipLaunchKernelGGL(syrk_rda_kernel<false>, dim3(ntiles), dim3(NTH), 0, s, g);
+    g.slab_t0 = slab ? slab_col0 / TB : 0; g.slab_nt = slab ? slab_cols / TB : 0;
+    const int ntiles = slab ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    if (slab) {
+        if (ids2) hipLaunchKernelGGL((syrk_rda_kernel<true, true>), dim3(ntiles), dim3(NTH), 0, s, g);
+        else hipLaunchKernelGGL((syrk_rda_kernel<false, true>), dim3(ntiles), dim3(NTH), 0, s, g);
+    } else {
+        if (ids2) hipLaunchKernelGGL((syrk_rda_kernel<true, false>), dim3(ntiles), dim3(NTH), 0, s, g);
+        else hipLaunchKernelGGL((syrk_rda_kernel<false, false>), dim3(ntiles), dim3(NTH), 0, s, g);
+    }
     DLCO_HIP(hipGetLastError());
     return true;
 }

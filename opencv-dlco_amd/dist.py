@@ -11,6 +11,13 @@ identically on every rank (same cv::RNG stream); rank g owns the batch slots
     all_reduce(GRAD, SUM)                                  (268 MB at F = 8192)
     finish : dual average + PSD projection, replicated
 
+That protocol moves F*F floats per step and stops scaling once the all-reduce (>= 0.44 ms at
+F = 8192 even on seven xGMI links) outweighs the 0.2 ms of gradient MFMA time.  ShardedTrainer
+is the scalable layout (SURVEY 8e "output sharding"): the dual average is sharded by columns,
+rank g computes its F x F/G slab of the gradient over the whole global batch and keeps it, and
+only the 2B distances and the m x F/G column slabs of the eigen tracker's ~6 products per step
+(m ~ 100 rows) are all-gathered — a few MB instead of 268 MB.
+
 The trainer below is backend-agnostic: `engine` is any object with the three phase methods
 and two torch tensors (`dist`, `grad`) that alias its exchange buffers.  The product engine
 is HipEngine (libdlco.so); the CPU tests drive the same class with an oracle-backed engine
@@ -69,3 +76,43 @@ class DataParallelTrainer:
     def steps(self, n):
         for _ in range(n):
             self.step()
+
+
+class ShardedTrainer:
+    """Column-sharded dual average (cfg.shard = 1): the whole step runs inside dlco_step and calls
+    back for its all-gathers, which are issued on the library's own HIP stream (no host sync)."""
+
+    def __init__(self, dlco, ctx, device, group=None):
+        self.dlco, self.ctx, self.group, self.device = dlco, ctx, group, device
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        _, nbytes = ctx.dev_buffer(dlco.BUF_GATHER)
+        self.gather = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.dist = torch.zeros(2 * ctx.B, dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        ctx.bind_buffer(dlco.BUF_GATHER, self.gather.data_ptr(), nbytes)
+        ctx.bind_buffer(dlco.BUF_DIST, self.dist.data_ptr(), self.dist.numel() * 4)
+        self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device)
+        self._views = {}
+        ctx.set_allgather(self._allgather)
+
+    def _allgather(self, which, nbytes):
+        if not dist.is_initialized():
+            return 0                                      # single rank without a process group: nothing to move
+        views = self._views.get((which, nbytes))
+        if views is None:                                 # a handful of distinct sizes per run
+            buf = self.dist if which == self.dlco.BUF_DIST else self.gather
+            n = nbytes // 4
+            full = buf[: n * self.world]
+            views = self._views[(which, nbytes)] = (full, full[self.rank * n:(self.rank + 1) * n], torch.empty_like(full[:n]))
+        full, mine, send = views
+        with torch.cuda.stream(self.stream):              # ordered on the library's stream, no host sync
+            send.copy_(mine)
+            dist.all_gather_into_tensor(full, send, group=self.group)
+        return 0
+
+    def step(self):
+        self.ctx.step()
+
+    def steps(self, n):
+        self.ctx.steps(n)

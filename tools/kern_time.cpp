@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <functional>
 #include <random>
 #include <vector>
 
@@ -95,6 +96,44 @@ int main()
         }
         std::printf("jacobi_eigh     n=%3d  %.1f us  sweeps %d (%.1f us/sweep)  |TV - VE|max = %.2e  |V^T V - I|max = %.2e\n", n,
                     msj * 1e3, sweeps, msj * 1e3 / std::max(1, sweeps), res, orth);
+    }
+    // ---- slab-mode kernels at the 8-GPU shape (F = 8192, slab of 1024 columns, global batch 1600+1600) ----
+    {
+        const int F = 8192, R = 4096, world = 8, cw = F / world;
+        DevBuf<float> D, C, X, out, slab; DevBuf<int32_t> ids; DevBuf<float> w; DevBuf<int> kd; DevBuf<char> ph, pl;
+        D.alloc((size_t)R * F); C.alloc((size_t)F * F); X.alloc((size_t)128 * F); out.alloc((size_t)128 * F);
+        slab.alloc((size_t)32 * 128 * F / 4); ids.alloc(3200); w.alloc(3200); kd.alloc(4);
+        ph.alloc(bf16x2_plane_bytes(128, F)); pl.alloc(bf16x2_plane_bytes(128, F));
+        std::vector<float> h((size_t)R * F);
+        for (auto &x : h) x = 0.1f * nd(rng);
+        hipMemcpy(D.p, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(X.p, h.data(), (size_t)128 * F * 4, hipMemcpyHostToDevice);
+        hipMemset(C.p, 0, (size_t)F * F * 4);
+        std::vector<int32_t> hid(3200); std::vector<float> hw(3200);
+        for (int i = 0; i < 3200; i++) { hid[i] = (int)(rng() % R); hw[i] = (float)(1 + rng() % 50); }
+        hipMemcpy(ids.p, hid.data(), 3200 * 4, hipMemcpyHostToDevice);
+        hipMemcpy(w.p, hw.data(), 3200 * 4, hipMemcpyHostToDevice);
+        for (int K : {224, 1696}) {
+            hipMemcpy(kd.p, &K, 4, hipMemcpyHostToDevice);
+            const float a = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.5f, C.p, F, s); });
+            const float b = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.5f, C.p, F, s, cw, cw); });
+            std::printf("syrk K=%4d  symmetric full %.1f us   column slab 1/%d (dense) %.1f us\n", K, a * 1e3, world, b * 1e3);
+        }
+        for (int M : {96}) {
+            const float a = time_ms(s, 20, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s); });
+            const float b = time_ms(s, 20, [&] { skinny_product_bf16x2(X.p, F, M, C.p + cw, F, cw, F, 1.f, out.p + cw, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s, 32); });
+            GemmArgs g;
+            g.M = M; g.N = cw; g.K = F;
+            g.A.p = X.p; g.A.ld = F; g.A.kmajor = false;
+            g.B.p = C.p + cw; g.B.ld = F; g.B.kmajor = true;
+            g.C = out.p + cw; g.ldc = F; g.split_k = 32; g.slab = slab.p;
+            const float c = time_ms(s, 20, [&] { gemm_f32(g, s); });
+            const float d = time_ms(s, 20, [&] { skinny_product_f32(X.p, F, M, 128, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, s); });
+            std::printf("product M=%d  bf16x2 full %.1f us, slab 1/%d (ks 32) %.1f us;  fp32 full (skinny) %.1f us, slab (gemm split 32) %.1f us\n",
+                        M, a * 1e3, world, b * 1e3, d * 1e3, c * 1e3);
+            const float e = time_ms(s, 20, [&] { pack_cols(slab.p, out.p, F, cw, cw, M, s); unpack_cols(out.p, F, slab.p, cw, M, world, s); });
+            std::printf("pack + unpack %.1f us\n", e * 1e3);
+        }
     }
     return 0;
 }
