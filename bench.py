@@ -142,7 +142,7 @@ def main():
     ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)        # identical bytes on every rank (dataset replicated)
     if use_dist:
         if shard:
-            trainer = ddist.ShardedTrainer(dlco, ctx, torch.device("cuda", local_rank))
+            trainer = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, ctx, torch.device("cuda", local_rank)))
         else:
             trainer = ddist.DataParallelTrainer(ddist.HipEngine(dlco, ctx, torch.device("cuda", local_rank)))
 

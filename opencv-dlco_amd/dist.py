@@ -78,14 +78,12 @@ class DataParallelTrainer:
             self.step()
 
 
-class ShardedTrainer:
-    """Column-sharded dual average (cfg.shard = 1): the whole step runs inside dlco_step and calls
-    back for its all-gathers, which are issued on the library's own HIP stream (no host sync)."""
+class HipShardEngine:
+    """A sharded libdlco.so context (cfg.shard = 1) whose exchange buffers are torch tensors."""
 
-    def __init__(self, dlco, ctx, device, group=None):
-        self.dlco, self.ctx, self.group, self.device = dlco, ctx, group, device
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    def __init__(self, dlco, ctx, device):
+        self.dlco, self.ctx, self.device = dlco, ctx, device
+        self.BUF_DIST, self.BUF_GATHER = dlco.BUF_DIST, dlco.BUF_GATHER
         _, nbytes = ctx.dev_buffer(dlco.BUF_GATHER)
         self.gather = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         self.dist = torch.zeros(2 * ctx.B, dtype=torch.float32, device=device)
@@ -93,26 +91,51 @@ class ShardedTrainer:
         ctx.bind_buffer(dlco.BUF_GATHER, self.gather.data_ptr(), nbytes)
         ctx.bind_buffer(dlco.BUF_DIST, self.dist.data_ptr(), self.dist.numel() * 4)
         self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device)
-        self._views = {}
-        ctx.set_allgather(self._allgather)
 
-    def _allgather(self, which, nbytes):
-        if not dist.is_initialized():
-            return 0                                      # single rank without a process group: nothing to move
-        views = self._views.get((which, nbytes))
-        if views is None:                                 # a handful of distinct sizes per run
-            buf = self.dist if which == self.dlco.BUF_DIST else self.gather
-            n = nbytes // 4
-            full = buf[: n * self.world]
-            views = self._views[(which, nbytes)] = (full, full[self.rank * n:(self.rank + 1) * n], torch.empty_like(full[:n]))
-        full, mine, send = views
-        with torch.cuda.stream(self.stream):              # ordered on the library's stream, no host sync
-            send.copy_(mine)
-            dist.all_gather_into_tensor(full, send, group=self.group)
-        return 0
+    def stream_guard(self):
+        return torch.cuda.stream(self.stream)             # collectives are ordered on the library's stream
+
+    def set_allgather(self, fn):
+        self.ctx.set_allgather(fn)
 
     def step(self):
         self.ctx.step()
 
     def steps(self, n):
         self.ctx.steps(n)
+
+
+class ShardedTrainer:
+    """Column-sharded dual average (cfg.shard = 1): the whole step runs inside the engine (for
+    HipShardEngine: dlco_step) and calls back for its all-gathers, which are issued on the engine's
+    own stream (no host sync).  `engine` provides the exchange tensors `dist` and `gather`, the ids
+    BUF_DIST / BUF_GATHER, `stream_guard()`, `set_allgather(fn)`, `step()`; the CPU tests drive the
+    same class with an oracle-backed engine over gloo."""
+
+    def __init__(self, engine, group=None):
+        self.e, self.group = engine, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._views = {}
+        engine.set_allgather(self._allgather)
+
+    def _allgather(self, which, nbytes):
+        if not dist.is_initialized():
+            return 0                                      # single rank without a process group: nothing to move
+        views = self._views.get((which, nbytes))
+        if views is None:                                 # a handful of distinct sizes per run
+            buf = self.e.dist if which == self.e.BUF_DIST else self.e.gather
+            n = nbytes // 4
+            full = buf[: n * self.world]
+            views = self._views[(which, nbytes)] = (full, full[self.rank * n:(self.rank + 1) * n], torch.empty_like(full[:n]))
+        full, mine, send = views
+        with self.e.stream_guard():
+            send.copy_(mine)
+            dist.all_gather_into_tensor(full, send, group=self.group)
+        return 0
+
+    def step(self):
+        self.e.step()
+
+    def steps(self, n):
+        self.e.steps(n)

@@ -177,7 +177,7 @@ def test_sharded_trainer_single_rank_path(dlco, monkeypatch):
     b = dlco.Context(F, N, B=B, mu=0.004, shard=1)
     a.set_data(D, L)
     b.set_data(D, L)
-    tr = ddist.ShardedTrainer(dlco, b, torch.device("cuda", 0))
+    tr = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, b, torch.device("cuda", 0)))
     a.steps(5)
     tr.steps(5)
     assert relmax(b.dfavg(), a.dfavg()) <= 5e-6
