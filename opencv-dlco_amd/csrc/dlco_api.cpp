@@ -46,6 +46,9 @@ struct dlco_ctx {
     DevBuf<float> dfavg, grad, W;
     int w_cap = 0;
     std::vector<int32_t> h_pos_rows, h_neg_rows;
+    int32_t *pin_ids = nullptr;      // pinned staging of the sampled row ids: [2 slots][2B], no sync after the upload
+    int *pin_k = nullptr;            // pinned read-back of the active row count
+    uint32_t upload_ctr = 0;
     DevBuf<int32_t> pos_rows, neg_rows, local_ids, rho, kappa, act_ids, seed_ids;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
     float *xdist = nullptr, *xgrad = nullptr;   // exchange buffers (own allocations unless bound by the caller)
@@ -250,11 +253,15 @@ void step_begin(dlco_ctx *c)
         c->h_pos_rows[k] = c->idx.pos[ip];
         c->h_neg_rows[k] = c->idx.neg[in];
     }
-    DLCO_HIP(hipMemcpyAsync(c->pos_rows.p, c->h_pos_rows.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->neg_rows.p, c->h_neg_rows.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->local_ids.p, c->h_pos_rows.data() + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->local_ids.p + Bl, c->h_neg_rows.data() + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    sync(c);   // host vectors are reused next step
+    // the upload reads a pinned slot that is not rewritten before the step after next (every step
+    // synchronises with the stream at least once in the tracker), so no sync is needed here
+    int32_t *slot = c->pin_ids + (size_t)(c->upload_ctr++ & 1u) * 2 * B;
+    std::memcpy(slot, c->h_pos_rows.data(), B * sizeof(int32_t));
+    std::memcpy(slot + B, c->h_neg_rows.data(), B * sizeof(int32_t));
+    DLCO_HIP(hipMemcpyAsync(c->pos_rows.p, slot, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->neg_rows.p, slot + B, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->local_ids.p, slot + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    DLCO_HIP(hipMemcpyAsync(c->local_ids.p + Bl, slot + B + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     // P1+P2 on this rank's slots -> its slice of the exchange buffer
     project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl);
     c->phase = 1;
@@ -308,14 +315,12 @@ void step_finish(dlco_ctx *c)
     }
     const float cscale = (float)(std::sqrt((double)c->t + 1.0) / (double)c->cfg.gamma);
     bool conv = true;
+    // rows that entered this rank's SYRK this step: read back with the tracker's own synchronisation
+    DLCO_HIP(hipMemcpyAsync(c->pin_k, c->k_active.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
     if (!conv) c->nonconv_steps++;
-    {
-        int k = 0;                                       // rows that entered this rank's SYRK this step
-        d2h(c, &k, c->k_active.p, sizeof(int));
-        c->active_rows_sum += k;
-        c->steps_run++;
-    }
+    c->active_rows_sum += *c->pin_k;                      // update() synchronised after the copy was queued
+    c->steps_run++;
     c->t++;
     c->phase = 0;
 }
@@ -450,6 +455,9 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->W.alloc((size_t)c->w_cap * c->F);
         const int B = c->B;
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
+        DLCO_HIP(hipHostMalloc((void **)&c->pin_ids, (size_t)4 * B * sizeof(int32_t)));
+        DLCO_HIP(hipHostMalloc((void **)&c->pin_k, 4 * sizeof(int)));
+        c->pin_k[0] = 0;
         c->pos_rows.alloc(B); c->neg_rows.alloc(B); c->local_ids.alloc(2 * c->Bl);
         c->rho.alloc(B); c->kappa.alloc(B);
         const int kcap = (2 * B + 31) & ~31;                      // row lists are zero padded to whole K tiles
@@ -484,6 +492,8 @@ void dlco_ctx_destroy(dlco_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->eig;
     if (c->roc) roc_work_destroy(c->roc);
+    if (c->pin_ids) (void)hipHostFree(c->pin_ids);
+    if (c->pin_k) (void)hipHostFree(c->pin_k);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -179,6 +179,10 @@ void axpby_inplace(float *y, const float *x, float a, float b, size_t n, hipStre
 void scale_rows(float *dst, long ldd, const float *src, long lds, const float *scale, const int32_t *src_rows,
                 int rows, int cols, hipStream_t s, const int32_t *src_rows2 = nullptr);    // dst[i] = scale[i]*(src[src_rows[i]] - src[src_rows2[i]])
 // out_a[i] = pa[ids ? ids[i] : base + i], out_b likewise: row ids -> (patch, patch) ids of the pair table
+// W[j][:] = sqrt(cscale * (theta[nw-1-j] - mu)) * Q[nw-1-j][:] for j < nw: the kept Ritz pairs in ascending
+// eigenvalue order, scaled like the reference's W = sqrt(e) * v^T (src/pj-learn.cpp:480-487)
+void emit_w_rows(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu, float cscale, int F,
+                 hipStream_t s);
 void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb, int32_t *out_a, int32_t *out_b,
                    hipStream_t s);
 void fill_f32(float *p, float v, size_t n, hipStream_t s);

@@ -404,7 +404,10 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         std::memcpy(h_res_.data(), pin_ + cap_, (size_t)m_ * sizeof(float));
         st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * cap_);
         have_theta_ = true;
-        drop_dead_rows();
+        {
+            const int before = m_;
+            theta_dev_valid_ = (drop_dead_rows() == before);    // a compaction leaves evals_ on the device stale
+        }
         theta_top = h_theta_[0];
         block_min = std::min(h_theta_[m_ - 1], mu);
 
@@ -461,19 +464,23 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     }
     double tr = 0.0;
     if (nw > 0) {
-        h_sc_.resize(nw);
-        h_sr_.resize(nw);
-        for (int j = 0; j < nw; j++) {
-            const int i = nw - 1 - j;
-            const float e = cscale * (h_theta_[i] - mu);
-            h_sc_[j] = std::sqrt(e);
-            h_sr_[j] = i;
-            tr += (double)e;
+        for (int i = 0; i < nw; i++) tr += (double)(cscale * (h_theta_[i] - mu));
+        if (theta_dev_valid_) {
+            // the Ritz values are still on the device in the order of the rows of Q: scale and reverse there
+            emit_w_rows(W, F_, Q_, F_, evals_.p, nw, mu, cscale, F_, s_);
+        } else {
+            h_sc_.resize(nw);
+            h_sr_.resize(nw);
+            for (int j = 0; j < nw; j++) {
+                const int i = nw - 1 - j;
+                h_sc_[j] = std::sqrt(cscale * (h_theta_[i] - mu));
+                h_sr_[j] = i;
+            }
+            DLCO_HIP(hipMemcpyAsync(scale_.p, h_sc_.data(), nw * sizeof(float), hipMemcpyHostToDevice, s_));
+            DLCO_HIP(hipMemcpyAsync(srcrow_.p, h_sr_.data(), nw * sizeof(int32_t), hipMemcpyHostToDevice, s_));
+            DLCO_HIP(hipStreamSynchronize(s_));
+            scale_rows(W, F_, Q_, F_, scale_.p, srcrow_.p, nw, F_, s_);
         }
-        DLCO_HIP(hipMemcpyAsync(scale_.p, h_sc_.data(), nw * sizeof(float), hipMemcpyHostToDevice, s_));
-        DLCO_HIP(hipMemcpyAsync(srcrow_.p, h_sr_.data(), nw * sizeof(int32_t), hipMemcpyHostToDevice, s_));
-        DLCO_HIP(hipStreamSynchronize(s_));
-        scale_rows(W, F_, Q_, F_, scale_.p, srcrow_.p, nw, F_, s_);
     }
     if (trace) *trace = tr;
     return nw;

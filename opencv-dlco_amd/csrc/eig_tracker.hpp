@@ -64,6 +64,7 @@ private:
     hipStream_t s_;
     int m_ = 0;                      // rows currently in the block
     bool have_theta_ = false;
+    bool theta_dev_valid_ = false;   // evals_ on the device matches h_theta_ row for row
     float lo_bound_ = 0.f;           // lower bound of H's spectrum
     bool have_lo_ = false;
     int steps_since_lo_ = 0;

@@ -225,6 +225,27 @@ __global__ void splitk_reduce_kernel(const float *slab, int split, int M, int N,
     }
 }
 
+// Few slices over a large output (the tracker's split-bf16 products: 4-32 slices of m x F): one
+// thread per four consecutive outputs, slices added in order, 16-byte accesses throughout.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float *slab, int split, int M, int N, float *C,
+                                                                 long ldc, float alpha, float beta, const float *E1,
+                                                                 float b1, const float *E2, float b2)
+{
+    const long total = (long)M * N, q = N >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)M * q; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / q), j = (int)(e % q) * 4;
+        const float *p = slab + (long)i * N + j;
+        f32x4 s = *reinterpret_cast<const f32x4 *>(p);
+        for (int z = 1; z < split; z++) s += *reinterpret_cast<const f32x4 *>(p + (long)z * total);
+        const long idx = (long)i * ldc + j;
+        f32x4 o = alpha * s;
+        if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4 *>(C + idx);
+        if (E1) o += b1 * *reinterpret_cast<const f32x4 *>(E1 + idx);
+        if (E2) o += b2 * *reinterpret_cast<const f32x4 *>(E2 + idx);
+        *reinterpret_cast<f32x4 *>(C + idx) = o;
+    }
+}
+
 // -----------------------------------------------------------------------------------------
 // Skinny product of the eigen tracker: out[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2
 // with M <= 128 (MT = ceil(M/32) row tiles), G row-major.  One workgroup owns 32 output
@@ -402,6 +423,16 @@ void splitk_reduce_f32(const float *slab, int split, int M, int N, float *C, lon
                        const float *E1, float b1, const float *E2, float b2, hipStream_t s)
 {
     const long total = (long)M * N;
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (split <= 32 && total >= 65536 && N % 4 == 0 && ldc % 4 == 0 && al16(slab) && al16(C) && (!E1 || al16(E1)) &&
+        (!E2 || al16(E2))) {
+        long blocks = (total / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, split, M, N, C, ldc, alpha,
+                           beta, E1, b1, E2, b2);
+        DLCO_HIP(hipGetLastError());
+        return;
+    }
     long blocks = (total * 16 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, split, M, N, C, ldc, alpha, beta,
@@ -477,14 +508,8 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
         launch<2, 2>(g, a.A.kmajor, a.B.kmajor, grid, s);
     }
     DLCO_HIP(hipGetLastError());
-    if (split > 1 && !a.raw_slab) {
-        const long total = (long)a.M * a.N;
-        long blocks = (total * 16 + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)a.slab, split, a.M, a.N,
-                           a.C, a.ldc, a.alpha, a.beta, a.E1, a.b1, a.E2, a.b2);
-        DLCO_HIP(hipGetLastError());
-    }
+    if (split > 1 && !a.raw_slab)
+        splitk_reduce_f32(a.slab, split, a.M, a.N, a.C, a.ldc, a.alpha, a.beta, a.E1, a.b1, a.E2, a.b2, s);
 }
 
 }  // namespace dlco

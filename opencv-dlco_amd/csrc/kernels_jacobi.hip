@@ -68,7 +68,7 @@ __device__ __forceinline__ void rotation(float a, float b, float c, float &t, fl
 // G: column-major, column j at G + j*ldc (ldc multiple of 4, entries [n, ldc) are zero)
 __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
                             float *scratch /* >= 4n floats, global */, int *sweeps_out, float *red /* LDS, JW+4 */,
-                            float *nrm /* n floats, LDS or global */)
+                            float *nrm /* n floats, LDS or global */, float stop_cos)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -185,7 +185,7 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
         // later rotations of the sweep disturb it only to second order: a sweep whose largest
         // cosine was m ends below ~n*m^2, so no separate verification sweep is run (the tracker
         // checks the residuals of the Ritz pairs it keeps anyway)
-        if (m <= 3e-4f) { sweep++; break; }
+        if (m <= stop_cos) { sweep++; break; }
     }
     if (tid == 0 && sweeps_out) *sweeps_out = sweep;
 
@@ -218,19 +218,19 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
 }
 
 __global__ __launch_bounds__(JT) void jacobi_lds_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
-                                                        long ldv, float *scratch, int *sweeps_out)
+                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos)
 {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     float *G = sh, *red = sh + (size_t)n * ldc, *nrm = red + JW + 4;
-    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm);
+    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm, stop_cos);
 }
 
 __global__ __launch_bounds__(JT) void jacobi_gmem_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
-                                                         long ldv, float *work, int *sweeps_out)
+                                                         long ldv, float *work, int *sweeps_out, float stop_cos)
 {
     __shared__ float red[JW + 4];
     float *G = work, *scratch = work + (size_t)n * ldc;
-    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n);
+    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos);
 }
 
 inline int col_stride(int n) { return (n + 3) & ~3; }
@@ -244,6 +244,8 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
 {
     DLCO_CHECK(n >= 1 && n <= 4096, -2, "jacobi_eigh: n out of range");
     const int ldc = col_stride(n);
+    // largest column cosine of a sweep below which the sweep is the last one (see the kernel)
+    static const float stop_cos = std::getenv("DLCO_JACOBI_STOP") ? (float)std::atof(std::getenv("DLCO_JACOBI_STOP")) : 1e-3f;
     if (n <= JACOBI_LDS_MAX_N) {
         const size_t lds = ((size_t)n * ldc + JW + 4 + n + 4) * sizeof(float);
         static bool attr_set = false;
@@ -252,9 +254,9 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(JT), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out);
+        hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(JT), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
     } else {
-        hipLaunchKernelGGL(jacobi_gmem_kernel, dim3(1), dim3(JT), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out);
+        hipLaunchKernelGGL(jacobi_gmem_kernel, dim3(1), dim3(JT), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
     }
     DLCO_HIP(hipGetLastError());
 }

@@ -174,6 +174,20 @@ __global__ void scale_rows_kernel(float *dst, long ldd, const float *src, long l
     }
 }
 
+__global__ void emit_w_kernel(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu,
+                              float cscale, int F)
+{
+    const int j = blockIdx.x;
+    if (j >= nw) return;
+    const int i = nw - 1 - j;
+    const float sc = sqrtf(cscale * (theta[i] - mu));
+    for (int c = threadIdx.x * 4; c < F; c += blockDim.x * 4) {
+        float4 v = *reinterpret_cast<const float4 *>(Q + (long)i * ldq + c);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *reinterpret_cast<float4 *>(W + (long)j * ldw + c) = v;
+    }
+}
+
 __global__ void translate_ids_kernel(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb,
                                      int32_t *out_a, int32_t *out_b)
 {
@@ -325,6 +339,14 @@ void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int wo
     if (rows <= 0) return;
     const long n4 = (long)world * rows * (cw / 4);
     hipLaunchKernelGGL(unpack_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, ld, src, cw, rows, world);
+    DLCO_HIP(hipGetLastError());
+}
+
+void emit_w_rows(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu, float cscale, int F,
+                 hipStream_t s)
+{
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(emit_w_kernel, dim3(nw), dim3(256), 0, s, W, ldw, Q, ldq, theta, nw, mu, cscale, F);
     DLCO_HIP(hipGetLastError());
 }
 
