@@ -186,9 +186,10 @@ int dlco_grad_rda(dlco_ctx *ctx, const int32_t *pos_rows_host, const int32_t *ne
 int dlco_psd_project(dlco_ctx *ctx, const float *dfavg_host, uint32_t t,
                      float *W_host, int32_t *r, float *A_host /* may be NULL */);
 /* Building block of E1 (no single reference line: the reference calls LAPACKE_ssyevr, :440):
- * out[rows,F] = X[rows,F] * G[F,F] for a symmetric G, rows <= 128.  mode 0 = exact fp32 MFMA
- * (used by the Rayleigh-Ritz step), mode 1 = split-bf16 MFMA with fp32 accumulation (used by
- * the Chebyshev filter; relative error ~1e-5). */
+ * out[rows,F] = X[rows,F] * G[F,F] for a symmetric G, rows <= 128.  mode 0 = fp32 MFMA (k-ordered
+ * fmaf chain), mode 1 = two-way split-bf16 MFMA with fp32 accumulation (the Chebyshev filter;
+ * relative error ~1e-5), mode 2 = three-way split-bf16 MFMA (the Rayleigh-Ritz product when
+ * F % 512 == 0; error at the level of fp32 rounding, ~1e-7). */
 int dlco_sym_product(dlco_ctx *ctx, const float *X_host, int32_t rows, const float *G_host, int32_t mode,
                      float *out_host);
 /* H1: sum_i sum_j max(pos_i + 1 - neg_j, 0)  (src/kernelop-opencv.cu:49-80). */

@@ -882,12 +882,14 @@ int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float
         h2d(c, X.p, X_host, (size_t)rows * F * sizeof(float));
         h2d(c, G.p, G_host, (size_t)F * F * sizeof(float));
         bool ok;
-        if (mode == 1) {
-            DevBuf<char> hi, lo;
+        if (mode == 1 || mode == 2) {
+            DevBuf<char> hi, lo, lo2;
             hi.alloc(bf16x2_plane_bytes(rows, F)); lo.alloc(bf16x2_plane_bytes(rows, F));
+            if (mode == 2) lo2.alloc(bf16x2_plane_bytes(rows, F));
             DevBuf<float> slab;
             slab.alloc(bf16x2_slab_floats(rows, F));
-            ok = skinny_product_bf16x2(X.p, F, rows, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, hi.p, lo.p, slab.p, c->stream);
+            ok = skinny_product_bf16x2(X.p, F, rows, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, hi.p, lo.p, slab.p,
+                                       c->stream, 0, mode == 2 ? lo2.p : nullptr);
             sync(c);
         } else {
             ok = skinny_product_f32(X.p, F, rows, pad, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, c->stream);

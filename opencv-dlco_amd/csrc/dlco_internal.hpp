@@ -137,11 +137,12 @@ void gemm_f32(const GemmArgs &a, hipStream_t s);
 // bf16x2_plane_bytes(M, K) bytes each.  Returns false for unsupported shapes.
 size_t bf16x2_plane_bytes(int M, int K);
 size_t bf16x2_slab_floats(int M, int N, int ksplit = 0);
+// plane_lo2 != nullptr selects the three-way split (x = hi + mid + lo, six MFMAs per term): fp32-level accuracy.
 // ksplit: number of K slices (grid y, default 4); K must be a multiple of 128 * ksplit.  A column slab of G
 // (N < K) takes ksplit = 4 * K / N so that the launch still fills the chip.
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
-                           float *slab, hipStream_t s, int ksplit = 0);
+                           float *slab, hipStream_t s, int ksplit = 0, void *plane_lo2 = nullptr);
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).

@@ -35,6 +35,8 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     if (bf16_filter_) {
         plane_hi_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
         plane_lo_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
+        // the Rayleigh-Ritz product takes the three-way split (fp32-level accuracy) unless DLCO_FP32_RR is set
+        if (std::getenv("DLCO_FP32_RR") == nullptr) plane_lo2_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
     }
     pv_.alloc(F_);
     pw_.alloc(F_);
@@ -107,11 +109,11 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         const float *E1s = E1 ? E1 + c0 : nullptr, *E2s = E2 ? E2 + c0 : nullptr;
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         bool done = false;
-        if (approx && bf16_filter_ && rows <= 128) {
+        if (bf16_filter_ && rows <= 128 && (approx || plane_lo2_.p)) {
             int ks = 4;                                              // keep ~256 workgroups in flight
             while (ks < 4 * world && F_ % (128 * ks * 2) == 0 && bf16x2_slab_floats(rows, cw, ks * 2) <= slab_floats_) ks *= 2;
             done = skinny_product_bf16x2(X, F_, rows, G + c0, F_, cw, F_, alpha, out + c0, F_, E1s, b1, E2s, b2, plane_hi_.p,
-                                         plane_lo_.p, slab_.p, s_, ks);
+                                         plane_lo_.p, slab_.p, s_, ks, approx ? nullptr : plane_lo2_.p);
         }
         if (!done) {
             GemmArgs g;
@@ -133,10 +135,11 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         unpack_cols(out, F_, shard_->gather, cw, rows, world, s_);
         return;
     }
-    if (approx && bf16_filter_ && rows <= 128 && F_ >= 256) {
+    if (bf16_filter_ && rows <= 128 && F_ >= 256 && (approx || plane_lo2_.p)) {
+        // filter products: two-way split (~1e-5); exact products (Rayleigh-Ritz): three-way split (~1e-7)
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         const bool ok = skinny_product_bf16x2(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p,
-                                              plane_lo_.p, slab_.p, s_);
+                                              plane_lo_.p, slab_.p, s_, 0, approx ? nullptr : plane_lo2_.p);
         if (prof_) prof_->end(PROF_EIG_PRODUCT);
         if (ok) return;
     }

@@ -81,7 +81,7 @@ private:
     DevBuf<int32_t> srcrow_;
     DevBuf<int> ibuf_;               // [0] kept count, [1] sweeps
     bool bf16_filter_ = false;       // filter products as split-bf16 MFMA (kernels_bf16x2.hip)
-    DevBuf<char> plane_hi_, plane_lo_;
+    DevBuf<char> plane_hi_, plane_lo_, plane_lo2_;
     DevBuf<int> dead_;               // dead-row flags of the panel being factored
     size_t slab_floats_ = 0;
     std::vector<float> h_theta_, h_res_, h_tmp_, h_sc_;

@@ -163,8 +163,9 @@ def test_grad_rda_fused_kernel(dlco, ref, F, B, zero_frac):
 
 @pytest.mark.parametrize("F,rows", [(256, 7), (512, 96), (1024, 128), (384, 40)])
 def test_tracker_product_kernels(dlco, F, rows):
-    """The two product kernels of the eigen tracker against fp64: exact-fp32 MFMA (Rayleigh-Ritz
-    step) and split-bf16 MFMA (Chebyshev filter only; stated error budget 3e-5 of |X||G|)."""
+    """The product kernels of the eigen tracker against fp64: fp32 MFMA, two-way split-bf16 MFMA
+    (Chebyshev filter only; stated error budget 3e-5 of |X||G|) and three-way split-bf16 MFMA
+    (Rayleigh-Ritz product; same budget as the fp32 kernel)."""
     rng = np.random.default_rng(F + rows)
     G = rng.standard_normal((F, F)).astype(np.float32)
     G = ((G + G.T) * 0.5).astype(np.float32)
@@ -180,6 +181,9 @@ def test_tracker_product_kernels(dlco, F, rows):
         got16 = ctx.sym_product(X, G, mode=1)
         assert (np.abs(got16 - want) <= 3e-5 * scale + 1e-30).all()
         assert np.abs(got16 - want).max() > 0                                  # it really is the approximate path
+        got24 = ctx.sym_product(X, G, mode=2)                                  # three-way split: fp32-level accuracy
+        assert (np.abs(got24 - want) <= 2e-6 * scale + 1e-30).all()
+        assert np.abs(got24 - want).max() <= 0.2 * np.abs(got16 - want).max()    # what is left is the fp32 accumulation
     ctx.close()
 
 
