@@ -492,8 +492,16 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
         g.slab = a.slab;
     }
     if (a.split_out) *a.split_out = split;
-    // tile choice: the small dimension decides
-    const bool small_m = a.M <= 64, small_n = a.N <= 64;
+    // tile choice: the small dimension decides; a launch that would leave most of the 256 CUs
+    // without a workgroup takes 64-wide tiles instead (the tracker's m x F x m products)
+    bool small_m = a.M <= 64, small_n = a.N <= 64;
+    auto n_wg = [&](bool sm, bool sn) {
+        return (long)((a.M + (sm ? 63 : 127)) / (sm ? 64 : 128)) * ((a.N + (sn ? 63 : 127)) / (sn ? 64 : 128)) * split;
+    };
+    if (!a.upper_only && std::getenv("DLCO_GEMM_BIG_TILES") == nullptr) {
+        if (!small_m && n_wg(small_m, small_n) < 256) small_m = true;
+        if (!small_n && n_wg(small_m, small_n) < 256) small_n = true;
+    }
     if (small_m && small_n) {
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, split);
         launch<1, 1>(g, a.A.kmajor, a.B.kmajor, grid, s);
