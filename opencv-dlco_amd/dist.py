@@ -117,6 +117,28 @@ class ShardedTrainer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._views = {}
+        # The callback runs about six times per step on the critical path, so it is kept to one
+        # torch call: the engine's stream becomes this thread's current stream once (instead of a
+        # context manager per call), and the all-gather is in place (send buffer = the rank's own
+        # chunk of the receive buffer, the layout NCCL/RCCL define as in-place) when the backend
+        # accepts it — probed here with a collective every rank takes part in.
+        self._inplace = False
+        if dist.is_initialized():
+            with engine.stream_guard():
+                probe = torch.zeros(self.world * 4, dtype=torch.float32, device=engine.dist.device)
+                probe[self.rank * 4:(self.rank + 1) * 4] = float(self.rank + 1)
+                try:
+                    dist.all_gather_into_tensor(probe, probe[self.rank * 4:(self.rank + 1) * 4], group=group)
+                    want = torch.arange(1, self.world + 1, dtype=torch.float32).repeat_interleave(4)
+                    ok = bool(torch.equal(probe.cpu(), want))
+                except Exception:                         # noqa: BLE001 - backend refuses aliased buffers
+                    ok = False
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.dist.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)    # all ranks must agree on the mode
+                self._inplace = bool(flag.item() == 1)
+        stream = getattr(engine, "stream", None)
+        if stream is not None:
+            torch.cuda.set_stream(stream)                 # collectives are ordered on the library's stream
         engine.set_allgather(self._allgather)
 
     def _allgather(self, which, nbytes):
@@ -127,9 +149,12 @@ class ShardedTrainer:
             buf = self.e.dist if which == self.e.BUF_DIST else self.e.gather
             n = nbytes // 4
             full = buf[: n * self.world]
-            views = self._views[(which, nbytes)] = (full, full[self.rank * n:(self.rank + 1) * n], torch.empty_like(full[:n]))
+            mine = full[self.rank * n:(self.rank + 1) * n]
+            views = self._views[(which, nbytes)] = (full, mine, None if self._inplace else torch.empty_like(mine))
         full, mine, send = views
-        with self.e.stream_guard():
+        if send is None:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
             send.copy_(mine)
             dist.all_gather_into_tensor(full, send, group=self.group)
         return 0
