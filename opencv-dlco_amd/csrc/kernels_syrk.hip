@@ -45,6 +45,7 @@ struct SyrkDev {
     float alpha, beta;
     int nt;                       // tiles per edge
     int slab_t0, slab_nt;         // column-slab mode: tile columns [slab_t0, slab_t0 + slab_nt) only
+    int stagger_from, stagger_units;   // workgroups [from, 2*from) sleep units * nk * 4096 cycles at start
 };
 
 union SyrkLds {
@@ -89,6 +90,17 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 
     const int kact = min(*g.k_dev, g.kmax);
     const int nk = (kact + KB - 1) / KB;          // the list is zero padded up to a multiple of KB
+
+    // Phase stagger.  A tile is an MFMA phase (K loop) followed by an HBM phase (512 KiB of dfAvg
+    // stored, 64 KiB prefetched for the next).  All tiles are alike, so the two workgroups that
+    // share a CU would run their K loops together (each at half the MFMA rate) and then store
+    // together (HBM idle meanwhile, MFMA idle afterwards).  The second workgroup of every CU in
+    // the first round starts about a quarter of a K loop late; the offset then persists from tile
+    // to tile and one workgroup computes while the other streams (measured: -6 % launch time at
+    // K = 224, neutral at K >= 1700; longer delays lose more at the start than they win).
+    if (g.stagger_units > 0 && bid >= g.stagger_from && bid < 2 * g.stagger_from) {
+        for (int q = 0; q < g.stagger_units * nk; q++) __builtin_amdgcn_s_sleep(64);
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -230,6 +242,18 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
     g.slab_t0 = slab ? slab_col0 / TB : 0; g.slab_nt = slab ? slab_cols / TB : 0;
     const int ntiles = slab ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    {
+        static int n_cu = 0, units = -1;
+        if (n_cu == 0) {
+            int dev = 0; hipDeviceProp_t prop;
+            DLCO_HIP(hipGetDevice(&dev));
+            DLCO_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            units = std::getenv("DLCO_SYRK_STAGGER") ? std::atoi(std::getenv("DLCO_SYRK_STAGGER")) : 1;
+        }
+        g.stagger_from = n_cu;
+        g.stagger_units = ntiles >= 4 * n_cu ? units : 0;      // only worth it over several rounds of tiles
+    }
     if (slab) {
         if (ids2) hipLaunchKernelGGL((syrk_rda_kernel<true, true>), dim3(ntiles), dim3(NTH), 0, s, g);
         else hipLaunchKernelGGL((syrk_rda_kernel<false, true>), dim3(ntiles), dim3(NTH), 0, s, g);

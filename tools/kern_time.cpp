@@ -113,6 +113,12 @@ int main()
         for (int i = 0; i < 3200; i++) { hid[i] = (int)(rng() % R); hw[i] = (float)(1 + rng() % 50); }
         hipMemcpy(ids.p, hid.data(), 3200 * 4, hipMemcpyHostToDevice);
         hipMemcpy(w.p, hw.data(), 3200 * 4, hipMemcpyHostToDevice);
+        for (int K : {0, 32, 64, 128, 224, 448, 896}) {                      // fixed cost vs per-K-tile cost of the SYRK
+            hipMemcpy(kd.p, &K, 4, hipMemcpyHostToDevice);
+            const float a = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.5f, C.p, F, s); });
+            const float b0 = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.0f, C.p, F, s); });
+            std::printf("syrk K=%4d  symmetric full: beta=0.5 %.1f us   beta=0 (no read of the old tile) %.1f us\n", K, a * 1e3, b0 * 1e3);
+        }
         for (int K : {224, 1696}) {
             hipMemcpy(kd.p, &K, 4, hipMemcpyHostToDevice);
             const float a = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.5f, C.p, F, s); });
