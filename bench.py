@@ -38,6 +38,31 @@ def make_U(F, k, seed):
     return (U * decay[:, None]).astype(np.float32)
 
 
+def make_pair_data(F, N, P, U, seed, sigma_pos=0.35, sigma_neg=1.0, noise=0.05):
+    """Pair mode stand-in for the reference's producer (src/comp-uprjdists.cpp:260-327): P per-patch
+    descriptors + the [N,4] Indices table.  Three patches per 3-D point; a descriptor is
+    U^T (c_point + s * delta_patch) + noise, so that a matching pair's difference has the latent
+    spread sigma_pos and a non-matching one about sigma_neg, like the row-mode generator."""
+    rng = np.random.default_rng(seed)
+    k = U.shape[0]
+    npts = P // 3
+    P = 3 * npts
+    point = (np.arange(P) % npts).astype(np.int32)
+    centre = (rng.standard_normal((npts, k)) * (sigma_neg / np.sqrt(2.0))).astype(np.float32)
+    desc = np.empty((P, F), np.float32)
+    for r0 in range(0, P, 8192):
+        r1 = min(P, r0 + 8192)
+        z = centre[point[r0:r1]] + (sigma_pos / np.sqrt(2.0)) * rng.standard_normal((r1 - r0, k)).astype(np.float32)
+        desc[r0:r1] = z @ U + (noise / np.sqrt(2.0)) * rng.standard_normal((r1 - r0, F)).astype(np.float32)
+    np.clip(desc, -1.0, 1.0, out=desc)
+    a = rng.integers(0, P, N).astype(np.int64)
+    b = rng.integers(0, P, N).astype(np.int64)
+    match = (np.arange(N) % 2 == 0)
+    b[match] = (a[match] + npts * rng.integers(1, 3, int(match.sum()))) % P      # another patch of the same point
+    pairs = np.stack([a, point[a], b, point[b]], axis=1).astype(np.int32)
+    return desc, pairs
+
+
 def pmc_traffic(F, bl):
     """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_syrk.json:
     separate FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC
@@ -93,6 +118,10 @@ def main():
     ap.add_argument("--latent", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--pair-mode", action="store_true",
+                    help="train from per-patch descriptors + the Indices table (dlco_set_pairs), differences formed "
+                         "inside the kernels, instead of the materialised Distance matrix")
+    ap.add_argument("--patches", type=int, default=65536, help="pair mode: number of patch descriptors")
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: run the N > 1 code path (process group, trainer, callbacks) with one rank")
     ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default="shard",
@@ -139,7 +168,12 @@ def main():
                        eig_guard=args.guard, eig_tol=args.eig_tol, shard=1 if shard else 0)
     dev_name, _, _ = ctx.device_name()
     U = make_U(F, args.latent, 2215 + 1)
-    ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)        # identical bytes on every rank (dataset replicated)
+    if args.pair_mode:
+        desc, pairs = make_pair_data(F, N, args.patches, U, 2215 + 1)
+        ctx.set_pairs(desc, pairs)                      # identical bytes on every rank (dataset replicated)
+        del desc
+    else:
+        ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)    # identical bytes on every rank (dataset replicated)
     if use_dist:
         if shard:
             trainer = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, ctx, torch.device("cuda", local_rank)))
@@ -206,7 +240,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "pj-learn Liberty-shaped %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
-                        % (N, F, Bl, Bl, B, B, args.mu, args.gamma, rank_now, args.warmup + args.steps),
+                        % (N, F, Bl, Bl, B, B, args.mu, args.gamma, rank_now, args.warmup + args.steps)
+                        + (" [pair mode: %d patch descriptors + Indices, differences formed in the kernels]" % args.patches
+                           if args.pair_mode else ""),
             "device": dev_name,
             "parallelism": ("dp%d (replicated data, batch slots sharded; dual average sharded by columns: all-gather of the "
                             "2B distances and of the tracker products' column slabs, no F x F exchange)" % world) if shard else
@@ -220,7 +256,7 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
-            "traffic": pmc_traffic(F, Bl) if world == 1 else None,
+            "traffic": pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else None,
             "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_syrk.json); algorithmic bytes 8*F*F + 4*K*F = %d" % int(8 * F * F + 4 * k_mean * F),
             "avg_launch_ms": ms_syrk / max(n_syrk, 1),
             "launches": n_syrk,
