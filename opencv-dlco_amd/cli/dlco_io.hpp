@@ -23,6 +23,8 @@ namespace dlco_io {
 inline bool is_h5(const std::string &p)
 {
     auto ends = [&](const char *s) { const size_t n = std::strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
+    struct stat st;
+    if (::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) return false;      // a directory of .npy files, whatever its name
     return ends(".h5") || ends(".hdf5") || ends(".hdf");
 }
 

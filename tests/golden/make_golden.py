@@ -8,6 +8,11 @@
                     reference holds (outputs of its own runs), converted from
                     HDF5 because h5py is not available on the test box.
   ref_log_head.txt  first lines of one reference log (stdout grammar fixture).
+  export_48.npz, vgg_generated_48.i.gz
+                    one "vgg_generated_XX.i" header the reference ships, with the W
+                    (from its result file) and pooling-region filters (recovered
+                    from the header itself) it was written from: golden vector of
+                    the export format (see make_export_fixture).
   oracle_*.npz      seeded input/output vectors produced by the CPU oracle
                     (oracle/dlco_ref.c).  They pin nothing against the
                     reference by themselves; they freeze the restatement so a
@@ -180,9 +185,43 @@ def make_oracle_vectors():
     print("oracle vectors written (blas: %s)" % ref.blas_kind())
 
 
+def make_export_fixture():
+    """export_48.npz + vgg_generated_48.i.gz: a header the reference ships
+    (workspace/opencv/vgg_generated_48.i, written by its export-opencv from the W of
+    workspace/pj-learn/notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5) together with its
+    inputs: W read from that result file, and the selected pooling-region filters recovered from
+    the header's own sparse PR arrays (the filters.h5 it was made from is not in the repository).
+    Output file + inputs = a golden vector for the export format."""
+    import gzip
+    src = "/root/reference/workspace/opencv/vgg_generated_48.i"
+    text = open(src, "rb").read()
+    body = text.decode()
+    def ints(name):
+        m = re.search(r"static const unsigned int %s\[\] =\n\{(.*?)\};" % name, body, re.S)
+        return [int(t, 16) for t in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
+    rows = int(re.search(r"PRrows = (\d+);", body).group(1))
+    cols = int(re.search(r"PRcols = (\d+);", body).group(1))
+    idx, vals = ints("PRidx"), np.array(ints("PR"), np.uint32).view(np.float32)
+    PR = np.zeros(rows * cols, np.float32)
+    k = 0
+    for start, count in zip(idx[0::2], idx[1::2]):
+        PR[start:start + count] = vals[k:k + count]
+        k += count
+    assert k == vals.size
+    read = h5_reader()
+    W = read(os.path.join(REF, "notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5"), "W")
+    np.savez_compressed(os.path.join(HERE, "export_48.npz"), PR=PR.reshape(rows, cols), W=W,
+                        prg=np.array("pr-learn/olderbest/yosemite-0.025-0.075-pr.h5"), widx=np.array(7),
+                        prj=np.array("pj-learn/notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5"))
+    with gzip.GzipFile(os.path.join(HERE, "vgg_generated_48.i.gz"), "wb", mtime=0) as f:
+        f.write(text)
+    print("export fixture: PR", PR.reshape(rows, cols).shape, "W", W.shape, "header bytes", len(text))
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
         make_ref_results()
+        make_export_fixture()
     else:
         print("reference not mounted: keeping existing ref_results.npz")
     make_oracle_vectors()
