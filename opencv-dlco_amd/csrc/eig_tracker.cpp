@@ -101,6 +101,16 @@ void EigTracker::append_random(float *Q, int have, int add)
 void EigTracker::product(const float *X, int rows, const float *G, float alpha, float *out, const float *E1, float b1,
                          const float *E2, float b2, bool approx)
 {
+    // the split-bf16 kernels take up to 128 rows: a taller block goes through them in row chunks
+    // (one HBM-bound pass over G per chunk, still cheaper than the generic fp32 GEMM)
+    if (rows > 128 && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
+        for (int r0 = 0; r0 < rows; r0 += 128) {
+            const int nr = std::min(128, rows - r0);
+            const size_t o = (size_t)r0 * F_;
+            product(X + o, nr, G, alpha, out + o, E1 ? E1 + o : nullptr, b1, E2 ? E2 + o : nullptr, b2, approx);
+        }
+        return;
+    }
     st_.product_rows += rows;
     if (shard_) {
         // the rank's column slab out[:, c0:c0+cw] = alpha * X * G[:, c0:c0+cw] + ..., then all-gather
