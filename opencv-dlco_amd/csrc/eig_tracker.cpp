@@ -369,6 +369,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             // cancellation against the amplified rows with ~1e5 * 6e-8 relative noise
             const int dcap = (int)(12.2f / std::acosh(xmax));
             d = std::max(2, std::min(d, dcap));
+            last_deg_ = d;
             const float *prev = Q_;
             float *cur = pick({Q_});
             product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f, true);
@@ -444,8 +445,9 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         else if (nw == 0) conv = guards_ok || it >= 6;
         else conv = crit <= tol_ * emax && guards_ok;
         if (debug_)
-            std::fprintf(stderr, "[eig] upd %ld it %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g conv %d\n",
-                         (long)st_.updates, it, m_, nw, h_theta_[0], h_theta_[m_ - 1], mu, lo_bound_, last_crit_, (int)conv);
+            std::fprintf(stderr, "[eig] upd %ld it %d deg %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g guards_ok %d conv %d\n",
+                         (long)st_.updates, it, last_deg_, m_, nw, h_theta_[0], h_theta_[m_ - 1], mu, lo_bound_, last_crit_,
+                         (int)guards_ok, (int)conv);
         if (h_theta_[m_ - 1] < lo_bound_) lo_bound_ = h_theta_[m_ - 1] - 0.5f * std::fabs(h_theta_[m_ - 1]) - 1e-12f;
         // ---- grow the block when the positive eigenspace reaches into the guard ------------------
         if (m_ < F_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {

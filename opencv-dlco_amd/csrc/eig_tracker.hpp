@@ -71,6 +71,7 @@ private:
     uint64_t rng_ = 0x243F6A8885A308D3ULL;
     float last_crit_ = 0.f;
     int deg0_ = 4;                   // filter degree of the first pass of a step (adapted)
+    int last_deg_ = 0;               // degree actually used by the last filter (after the amplification cap)
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
 
