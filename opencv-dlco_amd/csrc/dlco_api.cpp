@@ -49,7 +49,13 @@ struct dlco_ctx {
     int32_t *pin_ids = nullptr;      // pinned staging of the sampled row ids: [2 slots][2B], no sync after the upload
     int *pin_k = nullptr;            // pinned read-back of the active row count
     uint32_t upload_ctr = 0;
-    DevBuf<int32_t> pos_rows, neg_rows, local_ids, rho, kappa, act_ids, seed_ids;
+    // sampled row ids on the device, one allocation [pos: B | neg: B | own pos slots: Bl | own neg slots: Bl]
+    // filled by a single upload per step
+    struct IdView { int32_t *p = nullptr; };
+    DevBuf<int32_t> ids_all;
+    IdView pos_rows, neg_rows, local_ids;
+    const float *pd_cur = nullptr, *nd_cur = nullptr;    // distance vectors of the current step (see gather_dists)
+    DevBuf<int32_t> rho, kappa, act_ids, seed_ids;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
     float *xdist = nullptr, *xgrad = nullptr;   // exchange buffers (own allocations unless bound by the caller)
     DevBuf<int> k_active;
@@ -232,6 +238,21 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
     c->prof.end(PROF_GRAD_SYRK);
 }
 
+// Global distance vectors pd[B], nd[B] for the violation counts.  With one rank the exchange buffer
+// already is [pd | nd]; with several it is [world][pd slice | nd slice] and is regrouped.
+void gather_dists(dlco_ctx *c, const float **pd, const float **nd)
+{
+    const int Bl = c->Bl, world = c->cfg.world;
+    if (world == 1) { *pd = c->xdist; *nd = c->xdist + Bl; return; }
+    for (int g = 0; g < world; g++) {
+        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+    *pd = c->pd.p; *nd = c->nd.p;
+}
+
 void rda_coeffs(const dlco_ctx *c, float *alpha, float *beta)
 {
     // src/pj-learn.cpp:422: addWeighted(dfAvg, (double)t/(t+1), dLoss, 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg)
@@ -255,13 +276,13 @@ void step_begin(dlco_ctx *c)
     }
     // the upload reads a pinned slot that is not rewritten before the step after next (every step
     // synchronises with the stream at least once in the tracker), so no sync is needed here
-    int32_t *slot = c->pin_ids + (size_t)(c->upload_ctr++ & 1u) * 2 * B;
+    const size_t n_ids = (size_t)2 * B + 2 * Bl;
+    int32_t *slot = c->pin_ids + (size_t)(c->upload_ctr++ & 1u) * n_ids;
     std::memcpy(slot, c->h_pos_rows.data(), B * sizeof(int32_t));
     std::memcpy(slot + B, c->h_neg_rows.data(), B * sizeof(int32_t));
-    DLCO_HIP(hipMemcpyAsync(c->pos_rows.p, slot, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->neg_rows.p, slot + B, B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->local_ids.p, slot + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    DLCO_HIP(hipMemcpyAsync(c->local_ids.p + Bl, slot + B + c->lo, Bl * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    std::memcpy(slot + 2 * B, c->h_pos_rows.data() + c->lo, Bl * sizeof(int32_t));
+    std::memcpy(slot + 2 * B + Bl, c->h_neg_rows.data() + c->lo, Bl * sizeof(int32_t));
+    DLCO_HIP(hipMemcpyAsync(c->ids_all.p, slot, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     // P1+P2 on this rank's slots -> its slice of the exchange buffer
     project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl);
     c->phase = 1;
@@ -272,13 +293,9 @@ void step_grad(dlco_ctx *c)
     DLCO_CHECK(c->phase == 1, DLCO_ERR_INVALID, "dlco_step_grad: call dlco_step_begin first");
     DLCO_CHECK(!c->shard, DLCO_ERR_INVALID, "dlco_step_grad: a sharded context steps with dlco_step");
     const int B = c->B, Bl = c->Bl, world = c->cfg.world;
-    for (int g = 0; g < world; g++) {
-        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c->stream));
-        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c->stream));
-    }
-    viol_counts(c->pd.p, c->nd.p, B, c->rho.p, c->kappa.p, c->stream);
+    (void)world;
+    gather_dists(c, &c->pd_cur, &c->nd_cur);
+    viol_counts(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->stream);
     build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, c->lo, c->lo + Bl, c->act_ids.p,
                       c->act_w.p, c->k_active.p, c->stream);
     float alpha, beta;
@@ -333,14 +350,9 @@ void step_sharded(dlco_ctx *c)
 {
     step_begin(c);
     allgather(c, DLCO_BUF_DIST, (size_t)2 * c->Bl * sizeof(float));
-    const int B = c->B, Bl = c->Bl, world = c->cfg.world;
-    for (int g = 0; g < world; g++) {
-        DLCO_HIP(hipMemcpyAsync(c->pd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl, Bl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c->stream));
-        DLCO_HIP(hipMemcpyAsync(c->nd.p + (size_t)g * Bl, c->xdist + (size_t)g * 2 * Bl + Bl, Bl * sizeof(float),
-                                hipMemcpyDeviceToDevice, c->stream));
-    }
-    viol_counts(c->pd.p, c->nd.p, B, c->rho.p, c->kappa.p, c->stream);
+    const int B = c->B;
+    gather_dists(c, &c->pd_cur, &c->nd_cur);
+    viol_counts(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->stream);
     build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, 0, B, c->act_ids.p, c->act_w.p, c->k_active.p,
                       c->stream);
     float alpha, beta;
@@ -455,10 +467,11 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->W.alloc((size_t)c->w_cap * c->F);
         const int B = c->B;
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
-        DLCO_HIP(hipHostMalloc((void **)&c->pin_ids, (size_t)4 * B * sizeof(int32_t)));
+        DLCO_HIP(hipHostMalloc((void **)&c->pin_ids, (size_t)2 * (2 * B + 2 * c->Bl) * sizeof(int32_t)));
         DLCO_HIP(hipHostMalloc((void **)&c->pin_k, 4 * sizeof(int)));
         c->pin_k[0] = 0;
-        c->pos_rows.alloc(B); c->neg_rows.alloc(B); c->local_ids.alloc(2 * c->Bl);
+        c->ids_all.alloc((size_t)2 * B + 2 * c->Bl);
+        c->pos_rows.p = c->ids_all.p; c->neg_rows.p = c->ids_all.p + B; c->local_ids.p = c->ids_all.p + 2 * B;
         c->rho.alloc(B); c->kappa.alloc(B);
         const int kcap = (2 * B + 31) & ~31;                      // row lists are zero padded to whole K tiles
         c->act_ids.alloc(kcap); c->act_w.alloc(kcap); c->seed_ids.alloc(kcap); c->seed_w.alloc(kcap);
@@ -695,8 +708,9 @@ int dlco_get_batch(const dlco_ctx *cc, int32_t *pos_rows, int32_t *neg_rows, flo
         const size_t B = c->B;
         if (pos_rows) std::memcpy(pos_rows, c->h_pos_rows.data(), B * sizeof(int32_t));
         if (neg_rows) std::memcpy(neg_rows, c->h_neg_rows.data(), B * sizeof(int32_t));
-        if (pos_dist) d2h(c, pos_dist, c->pd.p, B * sizeof(float));
-        if (neg_dist) d2h(c, neg_dist, c->nd.p, B * sizeof(float));
+        DLCO_CHECK(c->pd_cur && c->nd_cur, DLCO_ERR_INVALID, "dlco_get_batch: no step has run");
+        if (pos_dist) d2h(c, pos_dist, c->pd_cur, B * sizeof(float));
+        if (neg_dist) d2h(c, neg_dist, c->nd_cur, B * sizeof(float));
         if (rho) d2h(c, rho, c->rho.p, B * sizeof(int32_t));
         if (kappa) d2h(c, kappa, c->kappa.p, B * sizeof(int32_t));
     });

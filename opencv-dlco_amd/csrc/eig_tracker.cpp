@@ -22,12 +22,13 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     Tm_.alloc((size_t)cap_ * cap_);
     Vm_.alloc((size_t)cap_ * cap_);
     Cw_.alloc((size_t)cap_ * cap_);
-    evals_.alloc(cap_ + 8);
-    res_.alloc(cap_ + 8);
+    ritz_block_.alloc((size_t)2 * (cap_ + 8) + 8);
+    evals_.p = ritz_block_.p;
+    res_.p = ritz_block_.p + (cap_ + 8);
+    sweeps_dev_ = reinterpret_cast<int *>(ritz_block_.p + 2 * (cap_ + 8));
     scale_.alloc(cap_ + 8);
     srcrow_.alloc(cap_ + 8);
     jwork_.alloc(jacobi_work_floats(cap_));
-    ibuf_.alloc(8);
     dead_.alloc(CHOL_INV_MAX_N);
     if (const char *e = std::getenv("DLCO_PANEL_AMP")) panel_amp_ = std::max(1.0, std::atof(e));
     // filter products run on the bf16 matrix cores with split operands unless DLCO_FP32_FILTER is set
@@ -44,7 +45,7 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     slab_floats_ = std::min(slab_floats_, (size_t)64 << 20);
     slab_floats_ = std::max(slab_floats_, (size_t)cap_ * F_);
     slab_.alloc(slab_floats_);
-    pin_floats_ = (size_t)3 * cap_ + 64;
+    pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats)
     DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float)));
     h_theta_.assign(cap_, 0.f);
     h_res_.assign(cap_, 0.f);
@@ -402,7 +403,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f, false);     // Yb = Qo * H, exact fp32
         gram(Yb, Qo, m_, Tm_.p);
         if (prof_) prof_->begin(PROF_JACOBI);
-        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, ibuf_.p + 1, s_);
+        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_);
         if (prof_) prof_->end(PROF_JACOBI);
         float *Qn = pick({Qo, Yb});
         rotate(Vm_.p, cap_, m_, m_, Qo, Qn);
@@ -410,13 +411,12 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         rotate(Vm_.p, cap_, m_, m_, Yb, Yn);
         Q_ = Qn; Y_ = Yn;
         residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
-        DLCO_HIP(hipMemcpyAsync(pin_, evals_.p, (size_t)m_ * sizeof(float), hipMemcpyDeviceToHost, s_));
-        DLCO_HIP(hipMemcpyAsync(pin_ + cap_, res_.p, (size_t)m_ * sizeof(float), hipMemcpyDeviceToHost, s_));
-        DLCO_HIP(hipMemcpyAsync(pin_ + 2 * cap_, ibuf_.p + 1, sizeof(int), hipMemcpyDeviceToHost, s_));
+        const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
+        DLCO_HIP(hipMemcpyAsync(pin_, ritz_block_.p, blk * sizeof(float), hipMemcpyDeviceToHost, s_));
         DLCO_HIP(hipStreamSynchronize(s_));
         std::memcpy(h_theta_.data(), pin_, (size_t)m_ * sizeof(float));
-        std::memcpy(h_res_.data(), pin_ + cap_, (size_t)m_ * sizeof(float));
-        st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * cap_);
+        std::memcpy(h_res_.data(), pin_ + (cap_ + 8), (size_t)m_ * sizeof(float));
+        st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * (cap_ + 8));
         have_theta_ = true;
         {
             const int before = m_;

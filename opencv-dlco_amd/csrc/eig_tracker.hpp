@@ -78,9 +78,14 @@ private:
     DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F
     float *all_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *Q_ = nullptr, *Y_ = nullptr;
-    DevBuf<float> Tm_, Vm_, Cw_, evals_, res_, jwork_, slab_, pv_, pw_, scale_;
+    DevBuf<float> Tm_, Vm_, Cw_, jwork_, slab_, pv_, pw_, scale_;
+    // Ritz values, residual norms and the Jacobi sweep count sit in one device block
+    // [evals: cap+8 | res: cap+8 | sweeps (int)] so that one copy brings them to the host
+    struct FView { float *p = nullptr; };
+    DevBuf<float> ritz_block_;
+    FView evals_, res_;
+    int *sweeps_dev_ = nullptr;
     DevBuf<int32_t> srcrow_;
-    DevBuf<int> ibuf_;               // [0] kept count, [1] sweeps
     bool bf16_filter_ = false;       // filter products as split-bf16 MFMA (kernels_bf16x2.hip)
     DevBuf<char> plane_hi_, plane_lo_, plane_lo2_;
     DevBuf<int> dead_;               // dead-row flags of the panel being factored
