@@ -465,3 +465,31 @@ def test_pair_mode_against_oracle(dlco, ref):
     assert checked >= 5
     ctx.close()
     tr.close()
+
+
+def test_config0_trajectory_band(dlco, ref):
+    """BASELINE configs[0] shape — 5 000 pair-rows, PR-dim 512, the reference's batch of 200+200,
+    mu chosen so that the learned rank settles near 32 — free-running for 300 steps on both sides.
+    The trajectories are chaotic in the hinge mask, so they are compared the way the metric is
+    stated: FPR@95 within +-0.1 % absolute, AUC +-1e-3, objective and rank in a narrow band."""
+    N, F, B = 5000, 512, 200
+    D, L = synth(N, F, k=40, seed=2215, sp=0.8, noise=0.25)        # hard enough that FPR95 is a few per cent
+    mu, gamma = 0.004, 0.5
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    for _ in range(300):
+        tr.step()
+    ctx.steps(300)
+    lo, rg, rank = ctx.validate()
+    lo_r, rg_r = tr.validate()
+    _, f95, auc = ctx.stats()
+    dim_r, f95_r, auc_r = tr.stats()
+    assert 8 <= dim_r <= 128 and 0.01 <= f95_r <= 0.2               # low-rank regime, non-trivial operating point
+    assert abs(rank - dim_r) <= 2
+    assert abs(f95 - f95_r) <= 1e-3 and abs(auc - auc_r) <= 1e-3
+    assert abs(lo - lo_r) <= 0.05 * max(lo_r, 1e-6) + 1e-4
+    assert abs(rg - rg_r) <= 0.05 * max(rg_r, 1e-6) + 1e-4
+    assert ctx.counters()["nonconverged"] == 0
+    ctx.close()
+    tr.close()
