@@ -257,7 +257,8 @@ def main():
             "device": dev_name,
             "burn_in_steps": args.burn_in,
             "parallelism": ("dp%d (replicated data, batch slots sharded; dual average sharded by columns: all-gather of the "
-                            "2B distances and of the tracker products' column slabs, no F x F exchange)" % world) if shard else
+                            "2B distances and of the tracker products' column slabs, no F x F exchange; collectives issued by %s)"
+                            % (world, "the library through RCCL" if getattr(trainer, "native", False) else "a torch.distributed callback")) if shard else
                            ("dp%d (replicated data, batch slots sharded, all-gather dists + all-reduce gradient)" % world),
             "combinations_per_s": float(B) * B * args.steps / dt,
         },

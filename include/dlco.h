@@ -142,6 +142,16 @@ int dlco_bind_buffer(dlco_ctx *ctx, int32_t which, void *dev_ptr, size_t bytes);
  * same sequence of calls.  The reference has no counterpart (single device). */
 typedef int (*dlco_allgather_fn)(void *user, int32_t which, size_t bytes_per_rank);
 int dlco_set_allgather(dlco_ctx *ctx, dlco_allgather_fn fn, void *user);
+/* Alternative to the callback: the library performs the all-gathers itself with RCCL
+ * (ncclAllGather over xGMI, in place, on its own stream; librccl is reached through dlopen:
+ * the copy already loaded in the process, else `rccl_path`, else the system one).  Rank 0 obtains
+ * a 128-byte ncclUniqueId with dlco_comm_unique_id, the host hands the same bytes to every rank
+ * (MPI, torch.distributed, a file ...), and every rank calls dlco_comm_init (a collective:
+ * ncclCommInitRank with cfg.rank / cfg.world).  A communicator, once created, takes precedence
+ * over the callback; dlco_comm_destroy (or dlco_ctx_destroy) releases it. */
+int dlco_comm_unique_id(void *out_id, size_t cap, const char *rccl_path);
+int dlco_comm_init(dlco_ctx *ctx, const void *id, size_t id_bytes, const char *rccl_path);
+int dlco_comm_destroy(dlco_ctx *ctx);
 /* The HIP stream the context launches on (as void*), so callers can order collectives. */
 int dlco_stream(dlco_ctx *ctx, void **stream);
 int dlco_sync(dlco_ctx *ctx);

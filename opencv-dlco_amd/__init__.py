@@ -94,6 +94,9 @@ def load():
     L.dlco_bind_buffer.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.dlco_stream.argtypes = [vp, C.POINTER(vp)]
     L.dlco_set_allgather.argtypes = [vp, ALLGATHER_FN, vp]
+    L.dlco_comm_unique_id.argtypes = [vp, C.c_size_t, C.c_char_p]
+    L.dlco_comm_init.argtypes = [vp, vp, C.c_size_t, C.c_char_p]
+    L.dlco_comm_destroy.argtypes = [vp]
     L.dlco_get_batch.argtypes = [vp, i32p, i32p, f32p, f32p, i32p, i32p]
     L.dlco_get_t.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.dlco_get_W.argtypes = [vp, f32p, i32p]
@@ -117,6 +120,16 @@ def load():
     L.dlco_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     _lib = L
     return L
+
+
+def comm_unique_id(rccl_path=None):
+    """128-byte ncclUniqueId for dlco_comm_init (rank 0 creates it, every rank receives the same bytes)."""
+    L = load()
+    buf = C.create_string_buffer(128)
+    rc = L.dlco_comm_unique_id(buf, 128, rccl_path.encode() if rccl_path else None)
+    if rc != OK:
+        raise DlcoError(rc, L.dlco_last_error(None).decode())
+    return buf.raw
 
 
 def exported_symbols():
@@ -246,6 +259,14 @@ class Context:
         p = C.c_void_p()
         self._ck(self.L.dlco_stream(self.h, C.byref(p)))
         return p.value
+
+    def comm_init(self, id_bytes, rccl_path=None):
+        """Collective: creates the library's own RCCL communicator from a 128-byte ncclUniqueId."""
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        self._ck(self.L.dlco_comm_init(self.h, buf, 128, rccl_path.encode() if rccl_path else None))
+
+    def comm_destroy(self):
+        self._ck(self.L.dlco_comm_destroy(self.h))
 
     def set_allgather(self, fn):
         """fn(which, bytes_per_rank) -> 0 on success; kept alive by the context (see dlco_set_allgather)."""

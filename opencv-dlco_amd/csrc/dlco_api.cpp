@@ -5,6 +5,7 @@
 #include "dlco_internal.hpp"
 #include "eig_tracker.hpp"
 #include "pair_index.hpp"
+#include "rccl_comm.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -82,6 +83,7 @@ struct dlco_ctx {
     DevBuf<float> gather_own;
     dlco_allgather_fn ag_fn = nullptr;
     void *ag_user = nullptr;
+    RcclComm *rccl = nullptr;        // direct RCCL communicator (dlco_comm_init); takes precedence over the callback
 };
 
 namespace {
@@ -110,6 +112,11 @@ void sync(dlco_ctx *c) { DLCO_HIP(hipStreamSynchronize(c->stream)); }
 // in-place all-gather of one of the exchange buffers through the host's collective (RCCL)
 void allgather(dlco_ctx *c, int32_t buffer_id, size_t bytes_per_rank)
 {
+    if (c->rccl) {                                            // RCCL over xGMI, on the library's own stream
+        void *buf = buffer_id == DLCO_BUF_DIST ? static_cast<void *>(c->xdist) : static_cast<void *>(c->comm.gather);
+        c->rccl->allgather_inplace(buf, bytes_per_rank, c->stream);
+        return;
+    }
     DLCO_CHECK(c->ag_fn != nullptr, DLCO_ERR_INVALID, "sharded step: no all-gather callback (dlco_set_allgather)");
     const int rc = c->ag_fn(c->ag_user, buffer_id, bytes_per_rank);
     if (rc != 0) throw Error(DLCO_ERR_COMM, "all-gather callback failed with code " + std::to_string(rc));
@@ -504,6 +511,7 @@ void dlco_ctx_destroy(dlco_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->eig;
+    delete c->rccl;
     if (c->roc) roc_work_destroy(c->roc);
     if (c->pin_ids) (void)hipHostFree(c->pin_ids);
     if (c->pin_k) (void)hipHostFree(c->pin_k);
@@ -695,6 +703,31 @@ int dlco_set_allgather(dlco_ctx *c, dlco_allgather_fn fn, void *user)
     c->ag_fn = fn;
     c->ag_user = user;
     return DLCO_OK;
+}
+
+int dlco_comm_unique_id(void *out_id, size_t cap, const char *rccl_path)
+{
+    if (!out_id || cap < 128) return DLCO_ERR_INVALID;
+    return guarded(nullptr, [&] { RcclComm::unique_id(out_id, rccl_path); });
+}
+
+int dlco_comm_init(dlco_ctx *c, const void *id, size_t id_bytes, const char *rccl_path)
+{
+    if (!c || !id || id_bytes < 128) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->shard, DLCO_ERR_INVALID, "dlco_comm_init: only a sharded context (cfg.shard) exchanges through the library");
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_comm_init: step in flight");
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        delete c->rccl;
+        c->rccl = nullptr;
+        c->rccl = new RcclComm(id, c->cfg.rank, c->cfg.world, rccl_path);
+    });
+}
+
+int dlco_comm_destroy(dlco_ctx *c)
+{
+    if (!c) return DLCO_ERR_INVALID;
+    return guarded(c, [&] { sync(c); delete c->rccl; c->rccl = nullptr; });
 }
 
 int dlco_sync(dlco_ctx *c) { return c ? guarded(c, [&] { sync(c); }) : DLCO_ERR_INVALID; }

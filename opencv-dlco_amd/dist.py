@@ -95,6 +95,37 @@ class HipShardEngine:
     def stream_guard(self):
         return torch.cuda.stream(self.stream)             # collectives are ordered on the library's stream
 
+    def enable_native_rccl(self, group=None):
+        """Collective over `group`: gives the library its own RCCL communicator (dlco_comm_init), so
+        that the step's all-gathers are ncclAllGather calls issued from C++ on the library's stream
+        with no Python in between.  Returns True when every rank succeeded; otherwise the
+        communicators are dropped again and the caller keeps the torch.distributed callback."""
+        import os
+        rank = dist.get_rank(group)
+        rccl_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(rccl_path):
+            rccl_path = None
+        ident = [None]
+        if rank == 0:
+            try:
+                ident[0] = self.dlco.comm_unique_id(rccl_path)
+            except Exception:                             # noqa: BLE001 - no usable librccl: everyone falls back
+                ident[0] = None
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ok = 0
+        if ident[0] is not None:
+            try:
+                self.ctx.comm_init(ident[0], rccl_path)
+                ok = 1
+            except Exception:                             # noqa: BLE001
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            self.ctx.comm_destroy()
+            return False
+        return True
+
     def set_allgather(self, fn):
         self.ctx.set_allgather(fn)
 
@@ -112,11 +143,18 @@ class ShardedTrainer:
     BUF_DIST / BUF_GATHER, `stream_guard()`, `set_allgather(fn)`, `step()`; the CPU tests drive the
     same class with an oracle-backed engine over gloo."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, native=None):
         self.e, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._views = {}
+        # Preferred: the library talks to RCCL itself (no Python on the step's critical path).  The
+        # torch.distributed callback below stays registered as the fallback.
+        import os
+        if native is None:
+            native = os.environ.get("DLCO_NATIVE_RCCL", "1") != "0"
+        self.native = bool(native and dist.is_initialized() and hasattr(engine, "enable_native_rccl")
+                           and engine.enable_native_rccl(group))
         # The callback runs about six times per step on the critical path, so it is kept to one
         # torch call: the engine's stream becomes this thread's current stream once (instead of a
         # context manager per call), and the all-gather is in place (send buffer = the rank's own

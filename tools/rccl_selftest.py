@@ -26,7 +26,8 @@ a = dlco.Context(F, N, B=B, mu=0.004)
 b = dlco.Context(F, N, B=B, mu=0.004, shard=1)
 a.set_data(D, L)
 b.set_data(D, L)
-tr = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, b, torch.device("cuda", 0)))
+tr = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, b, torch.device("cuda", 0)), native=(os.environ.get("DLCO_NATIVE_RCCL", "1") != "0"))
+print("native RCCL communicator:", tr.native)
 a.steps(20)
 tr.steps(20)
 b.sync()
