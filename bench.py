@@ -296,6 +296,8 @@ def main():
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if trainer is not None and hasattr(trainer, "close"):
+        trainer.close()                                   # torch's current stream must not outlive the context
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

@@ -175,9 +175,19 @@ class ShardedTrainer:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)    # all ranks must agree on the mode
                 self._inplace = bool(flag.item() == 1)
         stream = getattr(engine, "stream", None)
+        self._restore = None
         if stream is not None:
+            self._restore = torch.cuda.current_stream(engine.device)
             torch.cuda.set_stream(stream)                 # collectives are ordered on the library's stream
         engine.set_allgather(self._allgather)
+
+    def close(self):
+        """Gives this thread its previous torch stream back.  Call before the context is destroyed:
+        the library's stream dies with it, and torch must not be left pointing at it."""
+        if self._restore is not None:
+            torch.cuda.synchronize(self.e.device)
+            torch.cuda.set_stream(self._restore)
+            self._restore = None
 
     def _allgather(self, which, nbytes):
         if not dist.is_initialized():

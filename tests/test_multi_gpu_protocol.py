@@ -77,7 +77,7 @@ def test_single_rank_trainer_with_bound_buffers(dlco):
     b.close()
 
 
-def _run_sharded_ranks(dlco, D, L, F, N, B, mu, gamma, world, steps):
+def _run_sharded_ranks(dlco, D, L, F, N, B, mu, gamma, world, steps, pairs=None):
     """`world` sharded contexts on the one GPU of the box, one host thread each; the all-gather
     callback moves the peers' chunks by hand (what RCCL's all-gather does) between two barriers."""
     import threading
@@ -87,7 +87,10 @@ def _run_sharded_ranks(dlco, D, L, F, N, B, mu, gamma, world, steps):
     ctxs, bufs = [], []
     for r in range(world):
         c = dlco.Context(F, N, B=B, mu=mu, gamma=gamma, rank=r, world=world, shard=1)
-        c.set_data(D, L)
+        if pairs is None:
+            c.set_data(D, L)
+        else:
+            c.set_pairs(*pairs)                              # descriptors + Indices table (pair mode)
         _, nbytes = c.dev_buffer(dlco.BUF_GATHER)
         gather = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
         dist_t = torch.zeros(2 * B, dtype=torch.float32, device=dev)
@@ -182,5 +185,47 @@ def test_sharded_trainer_single_rank_path(dlco, monkeypatch):
     tr.steps(5)
     assert relmax(b.dfavg(), a.dfavg()) <= 5e-6
     assert relmax(b.A(), a.A()) <= 5e-4
+    tr.close()                                            # hand torch its own stream back before the context dies
+    torch.zeros(8, device="cuda").sum().item()            # torch is usable afterwards
     a.close()
     b.close()
+
+
+def test_sharded_pair_mode_equals_single_rank_row_mode(dlco):
+    """Both extensions at once: two sharded ranks fed with per-patch descriptors + the Indices table
+    against one rank fed with the materialised differences."""
+    from test_gpu_parity import _pair_case
+    N, F, B, P = 3000, 256, 40, 900
+    desc, pairs, D, L = _pair_case(N, F, P, seed=7)
+    mu, gamma, steps = 0.004, 0.5, 6
+    single = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    single.set_data(D, L)
+    single.steps(steps)
+    ctxs, _ = _run_sharded_ranks(dlco, None, None, F, N, B, mu, gamma, 2, steps, pairs=(desc, pairs))
+    bs = single.batch()
+    for c in ctxs:
+        b = c.batch()
+        for k in ("pos_rows", "neg_rows", "rho", "kappa"):
+            assert np.array_equal(b[k], bs[k]), k
+    assert np.array_equal(ctxs[0].W(), ctxs[1].W())
+    cw = F // 2
+    df = np.concatenate([ctxs[g].dfavg()[:, g * cw:(g + 1) * cw] for g in range(2)], axis=1)
+    assert relmax(df, single.dfavg()) <= 5e-6
+    assert relmax(ctxs[0].A(), single.A()) <= 5e-4
+    for c in ctxs:
+        c.close()
+    single.close()
+
+
+def test_comm_init_argument_checks(dlco):
+    """dlco_comm_init is only meaningful on a sharded context and needs a full 128-byte id."""
+    N, F, B = 500, 128, 8
+    D, L = synth(N, F, k=4, seed=60)
+    ctx = dlco.Context(F, N, B=B)
+    ctx.set_data(D, L)
+    with pytest.raises(dlco.DlcoError) as e:
+        ctx.comm_init(b"\0" * 128)
+    assert e.value.code == dlco.ERR_INVALID and "sharded" in str(e.value)
+    assert ctx.L.dlco_comm_init(ctx.h, None, 128, None) == dlco.ERR_INVALID
+    ctx.step()                                            # the context is still usable
+    ctx.close()

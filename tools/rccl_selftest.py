@@ -33,5 +33,6 @@ tr.steps(20)
 b.sync()
 print("dfavg relmax", relmax(b.dfavg(), a.dfavg()), "A relmax", relmax(b.A(), a.A()), "rank", a.W().shape[0], b.W().shape[0])
 assert relmax(b.dfavg(), a.dfavg()) <= 5e-6 and relmax(b.A(), a.A()) <= 5e-4
+tr.close()
 dist.destroy_process_group()
 print("rccl selftest ok")
