@@ -88,7 +88,7 @@ struct dlco_ctx {
 
 namespace {
 
-constexpr int VCHUNK = 16384;
+constexpr int VCHUNK = 65536;
 
 template <typename Fn>
 int guarded(const dlco_ctx *ctx, Fn &&fn)
