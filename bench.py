@@ -226,6 +226,12 @@ def main():
     ctx.profile_enable(False)
 
     rank_now = ctx.W().shape[0]
+    # where the trainer stands after the timed steps (outside the timed region): the reference's
+    # LogStep block, src/pj-learn.cpp:492-587 (validation objective, FPR@95 / AUC over all rows)
+    quality = None
+    if not shard:                                         # a sharded context validates the same replicated W
+        e = ctx.log_step()
+        quality = {"val_loss": e.loss_val, "regul": e.regul, "fpr95": e.fpr95, "auc": e.auc, "dim": e.dim}
     value = 2.0 * B * args.steps / dt
     # dominant kernel of the hot path: the fused weighted-SYRK gradient + dual average.
     # algorithmic flops per launch (dense, no symmetry credit): 2 * (2*Bl) * F^2
@@ -256,6 +262,7 @@ def main():
                            if args.pair_mode else ""),
             "device": dev_name,
             "burn_in_steps": args.burn_in,
+            "state_after_run": quality,
             "parallelism": ("dp%d (replicated data, batch slots sharded; dual average sharded by columns: all-gather of the "
                             "2B distances and of the tracker products' column slabs, no F x F exchange; collectives issued by %s)"
                             % (world, "the library through RCCL" if getattr(trainer, "native", False) else "a torch.distributed callback")) if shard else
