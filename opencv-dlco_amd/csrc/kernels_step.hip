@@ -27,7 +27,18 @@ __global__ void sqdist_kernel(const float *proj, int split, int r, int n, long l
     if (j >= n) return;
     const long plane = (long)r * ld;
     float d = 0.f;
-    for (int q = 0; q < r; q++) {
+    int q = 0;
+    if (split == 1) {
+        // eight independent loads in flight per trip; the squares are still added row after row
+        for (; q + 8 <= r; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = proj[(long)(q + u) * ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) d += v[u] * v[u];
+        }
+    }
+    for (; q < r; q++) {
         float p = 0.f;
         for (int z = 0; z < split; z++) p += proj[z * plane + (long)q * ld + j];
         d += p * p;
