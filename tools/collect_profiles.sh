@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.log
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/r1_bench_kernel_stats.csv
-python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 > $OUT/r1_bench_step_breakdown.txt
+python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/r1_bench_kernel_stats_timed.csv > $OUT/r1_bench_step_breakdown.txt
 rm -rf $OUT/stats
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
