@@ -92,6 +92,7 @@ float EigTracker::next_uniform()
 void EigTracker::append_random(float *Q, int have, int add)
 {
     if (add <= 0) return;
+    y_ok_ = false;
     h_tmp_.resize((size_t)add * F_);
     for (size_t i = 0; i < h_tmp_.size(); i++) h_tmp_[i] = next_uniform();
     DLCO_HIP(hipMemcpyAsync(Q + (size_t)have * F_, h_tmp_.data(), h_tmp_.size() * sizeof(float), hipMemcpyHostToDevice, s_));
@@ -336,6 +337,7 @@ void EigTracker::refresh_lower_bound(const float *G, int iters, float theta_top)
 int EigTracker::update(const float *G, float mu, float cscale, float *W, double *trace, bool *converged)
 {
     st_.updates++;
+    y_ok_ = false;                                                   // G changed since the last Rayleigh-Ritz step
     if (m_ == 0) {
         m_ = std::min(cap_, 2 * guard_ + 32);
         append_random(Q_, 0, m_);
@@ -348,7 +350,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     if (!have_lo_) refresh_lower_bound(G, 30, theta_top);
     else if (steps_since_lo_ >= period) refresh_lower_bound(G, 6, theta_top);
 
-    bool conv = false;
+    bool conv = false, cheap_done = false;
     int nw = 0, it = 0;
     int n_ritz = have_theta_ ? m_ : 0;        // leading rows that are Ritz vectors with a known theta
     std::vector<int> panel_ends;
@@ -370,16 +372,30 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             // cancellation against the amplified rows with ~1e5 * 6e-8 relative noise
             const int dcap = (int)(12.2f / std::acosh(xmax));
             d = std::max(2, std::min(d, dcap));
-            last_deg_ = d;
-            const float *prev = Q_;
-            float *cur = pick({Q_});
-            product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f, true);
-            for (int k = 2; k <= d; k++) {
-                float *nxt = pick({prev, cur});
-                product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f, true);
-                prev = cur; cur = nxt;
+            // A pass that missed the tolerance only narrowly is followed by a degree-1 pass that costs
+            // no product at all: Y = Q H is still there from the Rayleigh-Ritz step, and
+            // (H - c0) Q / e0 = (Y - c0 Q) / e0 already damps everything below the block by the
+            // factor the marginal case needs.
+            const bool cheap = it >= 1 && !cheap_done && y_ok_ && cheap_pass_ && last_crit_ <= 4.0f * tol_;
+            if (cheap) {
+                cheap_done = true;                                   // once per step: if it is not enough, filter properly
+                d = 1;
+                axpby_inplace(Y_, Q_, 1.0f / e0, -c0 / e0, (size_t)m_ * F_, s_);
+                Z = Y_;
+                y_ok_ = false;
+                st_.cheap_passes++;
+            } else {
+                const float *prev = Q_;
+                float *cur = pick({Q_});
+                product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f, true);
+                for (int k = 2; k <= d; k++) {
+                    float *nxt = pick({prev, cur});
+                    product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f, true);
+                    prev = cur; cur = nxt;
+                }
+                Z = cur;
             }
-            Z = cur;
+            last_deg_ = d;
             // panels: at most 128 rows, predicted amplification T_d(x_j) within panel_amp_ inside a
             // panel.  A Ritz row carries the directions above it only at the level of its own
             // residual, so after the filter it is at worst (residual level x amplification ratio)
@@ -410,6 +426,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         float *Yn = pick({Qo, Yb, Qn});
         rotate(Vm_.p, cap_, m_, m_, Yb, Yn);
         Q_ = Qn; Y_ = Yn;
+        y_ok_ = true;                                                // Y_ = Q_ H for the current H
         residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
         const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
         DLCO_HIP(hipMemcpyAsync(pin_, ritz_block_.p, blk * sizeof(float), hipMemcpyDeviceToHost, s_));

@@ -18,7 +18,7 @@
 namespace dlco {
 
 struct EigStats {
-    int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0;
+    int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0, cheap_passes = 0;
 };
 
 class EigTracker {
@@ -72,6 +72,8 @@ private:
     float last_crit_ = 0.f;
     int deg0_ = 4;                   // filter degree of the first pass of a step (adapted)
     int last_deg_ = 0;               // degree actually used by the last filter (after the amplification cap)
+    bool y_ok_ = false;              // Y_ = Q_ * H row for row for the matrix of the current update
+    bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
 
