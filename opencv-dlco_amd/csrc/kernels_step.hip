@@ -7,12 +7,6 @@ namespace dlco {
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ double wave_sum_d(double v)
 {
 #pragma unroll

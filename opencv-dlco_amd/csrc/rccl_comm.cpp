@@ -71,7 +71,7 @@ void RcclComm::unique_id(void *out128, const char *lib_path)
     std::memcpy(out128, &id, sizeof(id));
 }
 
-RcclComm::RcclComm(const void *id128, int rank, int world, const char *lib_path) : rank_(rank), world_(world)
+RcclComm::RcclComm(const void *id128, int rank, int world, const char *lib_path) : rank_(rank)
 {
     Api &a = api(lib_path);
     UniqueId id;

@@ -23,7 +23,7 @@ public:
 
 private:
     void *comm_ = nullptr;
-    int rank_ = 0, world_ = 1;
+    int rank_ = 0;
 };
 
 }  // namespace dlco
