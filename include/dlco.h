@@ -157,7 +157,8 @@ int dlco_stream(dlco_ctx *ctx, void **stream);
 int dlco_sync(dlco_ctx *ctx);
 
 /* Row ids (into Distance) of the last sampled batch and their squared distances
- * (src/pj-learn.cpp:311-314, 346-363); rho/kappa = violation counts (:373-376). */
+ * (src/pj-learn.cpp:311-314, 346-363); rho/kappa = violation counts (:373-376).
+ * Valid once a step has run (DLCO_ERR_INVALID before that). */
 int dlco_get_batch(const dlco_ctx *ctx, int32_t *pos_rows, int32_t *neg_rows,
                    float *pos_dist, float *neg_dist, int32_t *rho, int32_t *kappa);
 
