@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — pj-learn patch-pairs/sec on the BASELINE workload (config[1]):
+"""bench.py — pj-learn patch-pairs/sec on the BASELINE workload (configs[1]):
 Liberty-shaped 500k labelled pair-rows x PR-dim 8192, batch 200 positives + 200 negatives
 per GPU, fp32, learned rank ~64.  Synthetic data of that shape is generated in HBM (the
 Brown/Winder sets are not redistributable and there is no network).
@@ -9,6 +9,7 @@ sample the batch, project + squared distances, violation counts, fused weighted-
 gradient + dual average, PSD projection.  Nothing is skipped inside the timed region.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --config c3                      (configs[2]: the rank ~128 regime)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 The configuration BASELINE quotes is a trainer whose learned rank has settled near 64; from
@@ -17,6 +18,12 @@ iterations.  Reaching that state is part of building the workload, like generati
 `--burn-in` full steps (default 300, reported in config) run before the W warm-up steps, so
 that whatever --warmup / --steps the caller passes, the K timed steps are steps of the named
 configuration and not of the start-up transient.
+
+N > 1 (one process per GPU, RCCL): the headline `value` is weak scaling (per-GPU batch fixed,
+global batch N*200 + N*200) with the column-sharded dual average; the same invocation then
+measures, outside the headline's timed region and reported under `other_modes`, the literal
+contract of BASELINE configs[3] (replicated dual average + F x F all-reduce per step) and the
+same-global-batch (strong-scaling) mode of SURVEY 8(d) C4 (global 200 + 200 split over N).
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,6 +41,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (dense)
+PEAK_HBM_TBS = 8.0                # same guide: HBM3E spec peak (6.29 TB/s measured copy)
+
+# The two single-GPU workloads BASELINE.json names.  The generator (dlco_synth_data) draws
+# d = U^T z + noise*eps with a per-row log-normal scale, so that matches and non-matches overlap the
+# way real patch pairs do: FPR@95 of a few per cent at rank ~64-128 (the reference's liberty run
+# shows rank 71 / FPR95 9.19 % at step 500 and 67 / 5.67 % at the end:
+# workspace/pj-learn/logging/liberty-liberty-0.035-0.250-pr#7-0.0010-0.100-pj.log:23-24,423-424).
+# tests/test_full_width_gpu.py compares exactly these workloads with the oracle's ssyevr.
+WORKLOADS = {
+    "c2": dict(name="configs[1] Liberty-shaped, rank ~64", F=8192, N=500000, batch=200, mu=0.002, gamma=0.5,
+               latent=96, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.4, seed=2216,
+               rank_band=(48, 88), fpr95_band=(0.02, 0.15)),
+    "c3": dict(name="configs[2] NotreDame-shaped, rank ~128", F=8192, N=500000, batch=200, mu=0.0007, gamma=0.5,
+               latent=192, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.4, seed=2217,
+               rank_band=(100, 160), fpr95_band=(0.02, 0.15)),
+}
 
 
 def make_U(F, k, seed):
@@ -43,6 +66,21 @@ def make_U(F, k, seed):
     U /= np.linalg.norm(U, axis=1, keepdims=True)
     decay = (1.0 / (1.0 + np.arange(k) / 24.0)).astype(np.float32)
     return (U * decay[:, None]).astype(np.float32)
+
+
+def build_context(dlco, wl, B=None, device=0, rank=0, world=1, shard=0, data_from=None, **kw):
+    """A context on workload `wl` with its synthetic data resident in HBM.  `data_from` (another
+    context on the same device and workload) shares that context's Distance matrix instead of
+    generating a second copy."""
+    ctx = dlco.Context(wl["F"], wl["N"], B=B or wl["batch"], mu=wl["mu"], gamma=wl["gamma"], device=device, rank=rank,
+                       world=world, shard=shard, **kw)
+    if data_from is not None:
+        ptr, _ = data_from.dev_buffer(dlco.BUF_DATA)
+        ctx.set_data_device(ptr, (np.arange(wl["N"]) % 2 == 0).astype(np.uint8))
+    else:
+        ctx.synth_data(make_U(wl["F"], wl["latent"], wl["seed"]), wl["seed"], wl["sigma_pos"], wl["sigma_neg"],
+                       wl["noise"], wl["jitter"])
+    return ctx
 
 
 def make_pair_data(F, N, P, U, seed, sigma_pos=0.35, sigma_neg=1.0, noise=0.05):
@@ -70,46 +108,131 @@ def make_pair_data(F, N, P, U, seed, sigma_pos=0.35, sigma_neg=1.0, noise=0.05):
     return desc, pairs
 
 
-def pmc_traffic(F, bl):
-    """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_syrk.json:
-    separate FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC
-    counters cannot be read inside a timed run, so the figure is the committed one; it is only
-    reported for the configuration it was measured on."""
+def committed_profile(name):
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_syrk.json")))
-        if F == 8192 and bl == 200:
-            return d["hbm_bytes_per_launch_corrected"]
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
-        pass
-    return None
+        return None
 
 
-def cpu_baseline(ctx, F, B, mu, gamma, rows):
-    """The oracle (reference loop order, OpenBLAS sgemm/ssyevr) timed on this box's host cores
-    on a bounded sample: one full training step on a `rows`-row subset of the same data."""
+def pmc_traffic(F, bl):
+    """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC counters cannot be read
+    inside a timed run, so the figure is the committed one; it is only reported for the
+    configuration it was measured on."""
+    for name in ("r2_pmc_syrk.json", "r1_pmc_syrk.json"):
+        d = committed_profile(name)
+        if d and F == 8192 and bl == 200:
+            return d.get("hbm_bytes_per_launch_corrected"), name
+    return None, None
+
+
+def ncores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(ctx, wl, rows, steps, t0_step):
+    """The oracle (reference loop order, OpenBLAS sgemm/ssyevr) timed on this box's host cores on a
+    bounded sample: `steps` full training steps teacher-forced from the GPU's steady state (its
+    dual average, W and iteration counter after the timed run) on a `rows`-row subset of the same
+    synthetic data.  The "no-eigen" figure leaves out E1/E2 (ssyevr + the F^3 back-multiplication),
+    i.e. it is the reference's projection + gradient + dual average only."""
     from oracle import ref
 
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    nc = ncores()
     ref.lib()
-    kind = ref.blas_kind()
-    if kind != "openblas":
-        return {"value": None, "unit": "pair-rows/s", "cores": ncores, "kind": "port",
+    F, B, mu, gamma = wl["F"], wl["batch"], wl["mu"], wl["gamma"]
+    if ref.blas_kind() != "openblas":
+        return {"value": None, "unit": "pair-rows/s", "cores": nc, "kind": "port",
                 "sample": "skipped: no OpenBLAS found for the oracle's ssyevr at F=%d" % F}
-    ref.set_threads(ncores)
+    ref.set_threads(nc)
     D = ctx.get_rows(0, rows)
     L = (np.arange(rows) % 2 == 0).astype(np.uint8)
+    out = {"unit": "pair-rows/s", "cores": nc, "kind": "port"}
     tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=0)
-    t0 = time.perf_counter()
-    tr.step()
-    dt = time.perf_counter() - t0
+    tr.set_state(ctx.t(), ctx.dfavg(), ctx.W())
+    w0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    dt = time.perf_counter() - w0
+    tm = tr.timers()
     tr.close()
-    return {"value": 2.0 * B / dt, "unit": "pair-rows/s", "cores": ncores, "kind": "port",
-            "sample": "1 full step (t=0, reference loop order, OpenBLAS sgemm+ssyevr) at F=%d B=%d on a %d-row subset of the same synthetic data, %.1f s"
-                      % (F, B, rows, dt)}
+    no_eig = tm["project"] + tm["grad"] + tm["rda"]
+    out["value"] = 2.0 * B * steps / dt
+    out["no_eigen_value"] = 2.0 * B * steps / max(no_eig, 1e-9)
+    out["seconds_per_step"] = {"total": dt / steps, "project": tm["project"] / steps, "gradient": tm["grad"] / steps,
+                               "dual_average": tm["rda"] / steps, "eigen_ssyevr_and_backmultiply": tm["eig"] / steps}
+    out["sample"] = ("%d full steps (reference loop order, OpenBLAS sgemm + ssyevr) teacher-forced from the GPU's steady "
+                     "state (t=%d, its dfAvg and W) at F=%d B=%d on a %d-row subset of the same synthetic data, %.1f s; "
+                     "no_eigen_value = the same steps without E1/E2" % (steps, ctx.t(), F, B, rows, dt))
+    if t0_step:
+        tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=0)
+        w0 = time.perf_counter()
+        tr.step()
+        dt0 = time.perf_counter() - w0
+        tm0 = tr.timers()
+        tr.close()
+        out["worst_case_t0"] = {"value": 2.0 * B / dt0, "seconds": dt0, "gradient_seconds": tm0["grad"],
+                                "note": "first iteration from W = 0: every one of the B*B pairs violates (200 sgemms of F x F x 200)"}
+    return out
+
+
+def quality(ctx, wl, with_oracle):
+    """Where the trainer stands after the timed steps (outside the timed region): the reference's
+    LogStep block (src/pj-learn.cpp:492-587) on the GPU, and the SAME W scored by the oracle's
+    ROC sweep (src/misc.cpp:297-332) on the distances of all N rows."""
+    e = ctx.log_step()
+    q = {"val_loss": e.loss_val, "regul": e.regul, "fpr95": e.fpr95, "auc": e.auc, "dim": e.dim}
+    if with_oracle:
+        from oracle import ref
+        W = ctx.W()
+        d_all = ctx.project_sqdist(np.arange(wl["N"], dtype=np.int32), W)
+        f_o, a_o = ref.roc_stats(d_all, (np.arange(wl["N"]) % 2 == 0).astype(np.uint8))
+        q["oracle_on_same_W"] = {"fpr95": f_o, "auc": a_o, "abs_fpr95_diff": abs(f_o - e.fpr95),
+                                 "note": "oracle ROC sweep on the GPU's distances of all N rows; the +-0.1 % gate is "
+                                         "abs_fpr95_diff <= 1e-3 (tests/test_full_width_gpu.py also scores the oracle's "
+                                         "own ssyevr W)"}
+    return q
+
+
+class Runner:
+    """One trainer (context + optional distributed wrapper) and its timed run."""
+
+    def __init__(self, dlco, ctx, trainer, use_dist, torch=None, dist=None):
+        self.dlco, self.ctx, self.trainer, self.use_dist, self.torch, self.dist = dlco, ctx, trainer, use_dist, torch, dist
+
+    def run(self, n):
+        if self.trainer is None:
+            self.ctx.steps(n)
+        else:
+            self.trainer.steps(n)
+
+    def barrier(self):
+        self.ctx.sync()
+        if self.use_dist:
+            self.torch.cuda.synchronize()
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed(self, steps):
+        self.barrier()
+        t0 = time.perf_counter()
+        self.run(steps)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.use_dist:
+            tmax = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    def close(self):
+        if self.trainer is not None and hasattr(self.trainer, "close"):
+            self.trainer.close()                          # torch's current stream must not outlive the context
+        self.ctx.close()
 
 
 def main():
@@ -117,17 +240,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 = BASELINE configs[1] (rank ~64, the metric's configuration); c3 = configs[2] (rank ~128)")
     ap.add_argument("--burn-in", type=int, default=300,
-                    help="full training steps run while the workload is set up, to reach the rank ~64 regime the "
+                    help="full training steps run while the workload is set up, to reach the rank regime the "
                          "BASELINE configuration names (0 = time the start-up transient)")
-    ap.add_argument("--F", type=int, default=8192)
-    ap.add_argument("--N", type=int, default=500000)
-    ap.add_argument("--batch", type=int, default=200, help="pair-rows per class PER GPU")
-    ap.add_argument("--mu", type=float, default=0.002)
-    ap.add_argument("--gamma", type=float, default=0.5)
-    ap.add_argument("--latent", type=int, default=96)
+    ap.add_argument("--F", type=int, default=None)
+    ap.add_argument("--N", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="pair-rows per class PER GPU")
+    ap.add_argument("--mu", type=float, default=None)
+    ap.add_argument("--gamma", type=float, default=None)
+    ap.add_argument("--latent", type=int, default=None)
+    ap.add_argument("--jitter", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-t0", action="store_true", help="also time the worst-case first iteration (W = 0) on the CPU")
     ap.add_argument("--pair-mode", action="store_true",
                     help="train from per-patch descriptors + the Indices table (dlco_set_pairs), differences formed "
                          "inside the kernels, instead of the materialised Distance matrix")
@@ -135,8 +263,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: run the N > 1 code path (process group, trainer, callbacks) with one rank")
     ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default="shard",
-                    help="N > 1: column-sharded dual average (all-gathers of a few MB) or replicated dual "
-                         "average with an F x F all-reduce per step")
+                    help="N > 1 headline mode: column-sharded dual average (all-gathers of a few MB) or replicated "
+                         "dual average with an F x F all-reduce per step")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1 headline mode: per-GPU batch fixed (weak) or global batch fixed at --batch (strong)")
+    ap.add_argument("--no-other-modes", action="store_true", help="N > 1: measure the headline mode only")
     ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
     ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
     args = ap.parse_args()
@@ -151,10 +282,13 @@ def main():
             sys.exit(2)
 
     dlco = importlib.import_module("opencv-dlco_amd")
-    F, N, Bl = args.F, args.N, args.batch
-    B = Bl * world
+    wl = dict(WORKLOADS[args.config])
+    for k_, v_ in (("F", args.F), ("N", args.N), ("batch", args.batch), ("mu", args.mu), ("gamma", args.gamma),
+                   ("latent", args.latent), ("jitter", args.jitter)):
+        if v_ is not None:
+            wl[k_] = v_
+    F, N, Bl = wl["F"], wl["N"], wl["batch"]
 
-    trainer = None
     use_dist = world > 1 or args.force_dist
     if args.force_dist:
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -166,6 +300,7 @@ def main():
     real_stdout = os.dup(1)
     sys.stdout.flush()
     os.dup2(2, 1)
+    torch = dist = ddist = None
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -173,50 +308,42 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ddist = importlib.import_module("opencv-dlco_amd.dist")
-    shard = use_dist and args.dp_mode == "shard" and F % (128 * world) == 0
-    ctx = dlco.Context(F, N, B=B, mu=args.mu, gamma=args.gamma, device=local_rank, rank=rank, world=world,
-                       eig_guard=args.guard, eig_tol=args.eig_tol, shard=1 if shard else 0)
-    dev_name, _, _ = ctx.device_name()
-    U = make_U(F, args.latent, 2215 + 1)
-    if args.pair_mode:
-        desc, pairs = make_pair_data(F, N, args.patches, U, 2215 + 1)
-        ctx.set_pairs(desc, pairs)                      # identical bytes on every rank (dataset replicated)
-        del desc
-    else:
-        ctx.synth_data(U, 2215 + 1, 0.35, 1.0, 0.05)    # identical bytes on every rank (dataset replicated)
-    if use_dist:
-        if shard:
-            trainer = ddist.ShardedTrainer(ddist.HipShardEngine(dlco, ctx, torch.device("cuda", local_rank)))
-        else:
-            trainer = ddist.DataParallelTrainer(ddist.HipEngine(dlco, ctx, torch.device("cuda", local_rank)))
+    kw = dict(eig_guard=args.guard, eig_tol=args.eig_tol)
 
-    def run(n):
-        if trainer is None:
-            ctx.steps(n)
+    def make_runner(dp_mode, scaling, data_from=None):
+        """weak: global batch world*Bl; strong: global batch Bl (must divide by world)."""
+        Bg = Bl * world if scaling == "weak" else Bl
+        if Bg % world != 0:
+            return None
+        shard = use_dist and dp_mode == "shard" and F % (128 * world) == 0
+        if args.pair_mode:
+            ctx = dlco.Context(F, N, B=Bg, mu=wl["mu"], gamma=wl["gamma"], device=local_rank, rank=rank, world=world,
+                               shard=1 if shard else 0, **kw)
+            desc, pairs = make_pair_data(F, N, args.patches, make_U(F, wl["latent"], wl["seed"]), wl["seed"])
+            ctx.set_pairs(desc, pairs)                  # identical bytes on every rank (dataset replicated)
         else:
-            trainer.steps(n)
-
-    def barrier():
-        ctx.sync()
+            ctx = build_context(dlco, wl, B=Bg, device=local_rank, rank=rank, world=world, shard=1 if shard else 0,
+                                data_from=data_from, **kw)
+        trainer = None
         if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            dev = torch.device("cuda", local_rank)
+            trainer = (ddist.ShardedTrainer(ddist.HipShardEngine(dlco, ctx, dev)) if shard
+                       else ddist.DataParallelTrainer(ddist.HipEngine(dlco, ctx, dev)))
+        r = Runner(dlco, ctx, trainer, use_dist, torch, dist)
+        r.shard, r.Bg, r.dp_mode, r.scaling = shard, Bg, ("shard" if shard else "allreduce"), scaling
+        return r
 
-    run(args.burn_in)
-    run(args.warmup)
+    R = make_runner(args.dp_mode, args.scaling)
+    ctx = R.ctx
+    dev_name, _, _ = ctx.device_name()
+    B = R.Bg
+
+    R.run(args.burn_in)
+    R.run(args.warmup)
     ctx.profile_enable(True)
     es0 = ctx.eig_stats()
     cn0 = ctx.counters()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = R.timed(args.steps)
     es1 = ctx.eig_stats()
     cn1 = ctx.counters()
     n_syrk, ms_syrk = ctx.profile_read("grad_syrk")
@@ -226,22 +353,33 @@ def main():
     ctx.profile_enable(False)
 
     rank_now = ctx.W().shape[0]
-    # where the trainer stands after the timed steps (outside the timed region): the reference's
-    # LogStep block, src/pj-learn.cpp:492-587 (validation objective, FPR@95 / AUC over all rows)
-    quality = None
-    if not shard:                                         # a sharded context validates the same replicated W
-        e = ctx.log_step()
-        quality = {"val_loss": e.loss_val, "regul": e.regul, "fpr95": e.fpr95, "auc": e.auc, "dim": e.dim}
+    q = None
+    if not R.shard:                                       # a sharded context validates the same replicated W
+        q = quality(ctx, wl, with_oracle=(rank == 0 and world == 1 and not args.pair_mode))
     value = 2.0 * B * args.steps / dt
+    shard = R.shard
     # dominant kernel of the hot path: the fused weighted-SYRK gradient + dual average.
-    # algorithmic flops per launch (dense, no symmetry credit): 2 * (2*Bl) * F^2
-    # only rows with a non-zero violation count enter the SYRK (the reference skips them too,
-    # src/pj-learn.cpp:378), so the per-launch figure uses the measured mean row count K <= 2*Bl.
+    # algorithmic flops per launch (dense, no symmetry credit): 2 * K * F^2 where K is the
+    # measured mean number of rows with a non-zero violation count (the reference skips the others
+    # too, src/pj-learn.cpp:378), K <= 2*B.
     k_mean = (cn1["active_rows"] - cn0["active_rows"]) / max(cn1["steps"] - cn0["steps"], 1)
     flops_launch = 2.0 * k_mean * F * F
     if shard:                      # the rank's launch covers its F x F/world column slab over the whole global batch
         flops_launch /= world
-    ach = flops_launch / (ms_syrk / max(n_syrk, 1) * 1e-3) / 1e12 if n_syrk else None
+    t_syrk = ms_syrk / max(n_syrk, 1) * 1e-3
+    ach = flops_launch / t_syrk / 1e12 if n_syrk else None
+    exec_flops = flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128))
+    traffic, traffic_src = pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else (None, None)
+    sq = committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
+    mfma_busy = None
+    try:
+        mfma_busy = sq["kernels"]["syrk_rda_kernel"]["mfma_util"]
+    except Exception:
+        pass
+    # per pair-row 2F^2 + 2Fr flops (projection + gradient, dense)
+    flops_pair_row = 2.0 * F * F + 2.0 * F * rank_now
+    t_kernel_path = (ms_syrk + ms_prj) / args.steps * 1e-3          # P1+P2 + Q1+U1 per step, HIP events
+    t_prod = ms_prod / max(n_prod, 1) * 1e-3
     out = {
         "metric": "pj-learn patch-pairs/sec",
         "value": value,
@@ -251,21 +389,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": R.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "pj-learn Liberty-shaped %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
-                        % (N, F, Bl, Bl, B, B, args.mu, args.gamma, rank_now, args.burn_in + args.warmup + args.steps)
+            "workload": "pj-learn %s: %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
+                        % (wl["name"], N, F, B // world, B // world, B, B, wl["mu"], wl["gamma"], rank_now,
+                           args.burn_in + args.warmup + args.steps)
                         + (" [pair mode: %d patch descriptors + Indices, differences formed in the kernels]" % args.patches
                            if args.pair_mode else ""),
+            "generator": {k_: wl[k_] for k_ in ("latent", "sigma_pos", "sigma_neg", "noise", "jitter", "seed")},
             "device": dev_name,
             "burn_in_steps": args.burn_in,
-            "state_after_run": quality,
+            "state_after_run": q,
             "parallelism": ("dp%d (replicated data, batch slots sharded; dual average sharded by columns: all-gather of the "
                             "2B distances and of the tracker products' column slabs, no F x F exchange; collectives issued by %s)"
-                            % (world, "the library through RCCL" if getattr(trainer, "native", False) else "a torch.distributed callback")) if shard else
+                            % (world, "the library through RCCL" if getattr(R.trainer, "native", False) else "a torch.distributed callback")) if shard else
                            ("dp%d (replicated data, batch slots sharded, all-gather dists + all-reduce gradient)" % world),
             "combinations_per_s": float(B) * B * args.steps / dt,
         },
@@ -276,13 +416,28 @@ def main():
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
-            "traffic": pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else None,
-            "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_syrk.json); algorithmic bytes 8*F*F + 4*K*F = %d" % int(8 * F * F + 4 * k_mean * F),
-            "avg_launch_ms": ms_syrk / max(n_syrk, 1),
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s); algorithmic bytes 8*F*F + 4*K*F = %d"
+                            % (traffic_src, int(8 * F * F + 4 * k_mean * F)),
+            "avg_launch_ms": t_syrk * 1e3,
             "launches": n_syrk,
             "algorithmic_flops_per_launch": flops_launch,
             "mean_active_rows_per_launch": k_mean,
-            "executed_flops_per_launch": flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128)),
+            "executed_flops_per_launch": exec_flops,
+            # the kernel computes the upper tiles only: executed/peak is what the MFMA pipe really does
+            "executed_frac": (exec_flops / t_syrk / 1e12 / PEAK_F32_MFMA_TFLOPS) if n_syrk else None,
+            "mfma_busy_frac_pmc": mfma_busy,
+            # kernel path only (P1+P2+V1+Q1+U1), (ii) end to end incl. the PSD projection
+            "flops_per_pair_row": flops_pair_row,
+            "kernel_path_frac": (2.0 * B / world * flops_pair_row / t_kernel_path / 1e12 / PEAK_F32_MFMA_TFLOPS) if t_kernel_path > 0 else None,
+            "end_to_end_frac": value / world * flops_pair_row / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "tracker_product": {
+                "kernel": "one pass of the eigen tracker over dfAvg (split-bf16 MFMA), HBM-bound",
+                "avg_launch_ms": t_prod * 1e3 if n_prod else None,
+                "launches_per_step": n_prod / args.steps,
+                "algorithmic_bytes_per_launch": 4.0 * F * F / (world if shard else 1),
+                "hbm_frac": (4.0 * F * F / (world if shard else 1) / t_prod / 1e12 / PEAK_HBM_TBS) if n_prod else None,
+            },
             "tracker_nonconverged_steps": cn1["nonconverged"] - cn0["nonconverged"],
         },
         "breakdown_ms_per_step": {
@@ -296,16 +451,32 @@ def main():
             "eig_block_rows": es1["block_rows"],
         },
     }
+    # ---- N > 1: the other two modes SURVEY 8(d)/(e) and BASELINE configs[3] name, measured after the headline
+    if world > 1 and not args.no_other_modes and not args.pair_mode:
+        others = {}
+        for dp_mode, scaling in (("allreduce", "weak"), ("shard", "strong")):
+            if dp_mode == R.dp_mode and scaling == R.scaling:
+                dp_mode, scaling = "shard", "weak"
+            r2 = make_runner(dp_mode, scaling, data_from=ctx)
+            if r2 is None:
+                continue
+            r2.run(args.burn_in)
+            r2.run(args.warmup)
+            dt2 = r2.timed(args.steps)
+            others["%s_%s" % (r2.dp_mode, scaling)] = {
+                "value": 2.0 * r2.Bg * args.steps / dt2, "unit": "pair-rows/s", "ms_per_step": dt2 / args.steps * 1e3,
+                "global_batch": "%d+%d" % (r2.Bg, r2.Bg), "scaling": scaling, "dp_mode": r2.dp_mode,
+                "rank": int(r2.ctx.W().shape[0]), "nonconverged": r2.ctx.counters()["nonconverged"]}
+            r2.close()
+        out["other_modes"] = others
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, F, Bl, args.mu, args.gamma, args.cpu_rows)
+        if world == 1 and not args.no_cpu_baseline and not args.pair_mode:
+            out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_rows, args.cpu_steps, args.cpu_t0)
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if trainer is not None and hasattr(trainer, "close"):
-        trainer.close()                                   # torch's current stream must not outlive the context
-    ctx.close()
+    R.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -47,13 +47,19 @@ typedef struct dlco_cfg {
     float    eig_tol;    /* subspace tracker tolerance on c*|residual| / max e (default 2e-4) */
     int32_t  eig_guard;  /* guard vectors kept beyond the positive eigenspace (default 32)  */
     int32_t  eig_max_iter; /* filter+Rayleigh-Ritz iterations per step before giving up      */
+                          /* The tracker block holds at most min(F, max(1024, 2*B + 2*eig_guard)) rows (positive
+                           * rank + guards); a positive eigenspace that does not fit is reported as a
+                           * non-converged step, never truncated silently.                              */
     int32_t  shard;      /* world > 1 only.  0: every rank keeps the whole dual average, the F x F
                           * partial gradients are all-reduced (dlco_step_begin/grad/finish).
                           * 1: the dual average is sharded by columns, rank g owns columns
                           * [g*F/world, (g+1)*F/world); no F x F exchange, the step (dlco_step) calls
                           * the all-gather registered with dlco_set_allgather.  F % (128*world) == 0
                           * selects the fused kernels.                                            */
-    int32_t  reserved[7];
+    int32_t  strict_conv; /* 1: dlco_step returns DLCO_ERR_NOCONV when the tracker misses eig_tol (the step is
+                          * still applied).  0 (default): the miss is counted (dlco_counters out[2],
+                          * dlco_log_entry.nonconv) and the run goes on with the approximate W.            */
+    int32_t  reserved[6];
 } dlco_cfg;
 
 void dlco_cfg_default(dlco_cfg *cfg);
@@ -86,9 +92,10 @@ int dlco_set_data_device(dlco_ctx *ctx, const float *dists_dev, const uint8_t *l
 int dlco_set_pairs(dlco_ctx *ctx, const float *desc_host, int32_t P, const int32_t *pairs_host);
 /* Bench helper (no reference counterpart: the Brown/Winder sets are not redistributable):
  * fills the context's Distance matrix in HBM with d = U^T z + noise*eps clipped to [-1,1],
+ * z ~ N(0, (sigma * s_i)^2 I_k), s_i = exp(scale_jitter * g_i) a per-row log-normal scale (0 = none),
  * label = 1 for even rows; U is [k,F] on the host. */
 int dlco_synth_data(dlco_ctx *ctx, const float *U_host, int32_t k, uint64_t seed,
-                    float sigma_pos, float sigma_neg, float noise);
+                    float sigma_pos, float sigma_neg, float noise, float scale_jitter);
 /* Copies `n` rows [row0, row0+n) of the device-resident Distance matrix back to the host. */
 int dlco_get_rows(dlco_ctx *ctx, int32_t row0, int32_t n, float *out_host);
 
@@ -124,6 +131,9 @@ int dlco_step_finish(dlco_ctx *ctx);
 #define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
 #define DLCO_BUF_GATHER 5   /* f32 [world][rows*F/world]: column slabs of a tracker product
                                (sharded contexts only)                                   */
+#define DLCO_BUF_DATA   6   /* f32 [N*F] (row mode) or [P*F] (pair mode): the resident Distance /
+                               descriptor matrix, e.g. to share it with a second context through
+                               dlco_set_data_device                                         */
 /* Device pointer and byte size of an exchange buffer (valid until ctx is destroyed). */
 int dlco_dev_buffer(dlco_ctx *ctx, int32_t which, void **dev_ptr, size_t *bytes);
 /* Makes the context use caller-owned device memory for an exchange buffer (DLCO_BUF_DIST,
@@ -221,6 +231,9 @@ typedef struct dlco_log_entry {
     double   auc, auc_best;
     float    fpr95, fpr95_best;
     double   vtime;        /* seconds spent in this call (Vtime) */
+    int32_t  nonconv;      /* training steps since the previous dlco_log_step whose eigen tracker stopped
+                              short of eig_tol (no reference counterpart: LAPACKE_ssyevr is direct)      */
+    int32_t  reserved;
 } dlco_log_entry;
 /* Runs the LogStep block once: validation, best-objective test, stats and save rule.
  * Keeps W_Best / W_Save / A_Save inside the context. */

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libdlco.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dlco.h")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NODEVICE, ERR_NOCONV, ERR_COMM = 0, -2, -3, -4, -5, -6
-BUF_DIST, BUF_GRAD, BUF_DFAVG, BUF_W, BUF_GATHER = 1, 2, 3, 4, 5
+BUF_DIST, BUF_GRAD, BUF_DFAVG, BUF_W, BUF_GATHER, BUF_DATA = 1, 2, 3, 4, 5, 6
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_size_t)
 
 
@@ -35,8 +35,8 @@ class Cfg(C.Structure):
         ("seed", C.c_uint64),
         ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
         ("eig_tol", C.c_float), ("eig_guard", C.c_int32), ("eig_max_iter", C.c_int32),
-        ("shard", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("shard", C.c_int32), ("strict_conv", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -48,6 +48,7 @@ class LogEntry(C.Structure):
         ("auc", C.c_double), ("auc_best", C.c_double),
         ("fpr95", C.c_float), ("fpr95_best", C.c_float),
         ("vtime", C.c_double),
+        ("nonconv", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -84,7 +85,7 @@ def load():
     L.dlco_set_data.argtypes = [vp, f32p, u8p]
     L.dlco_set_data_device.argtypes = [vp, vp, u8p]
     L.dlco_set_pairs.argtypes = [vp, f32p, C.c_int32, i32p]
-    L.dlco_synth_data.argtypes = [vp, f32p, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_float]
+    L.dlco_synth_data.argtypes = [vp, f32p, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float]
     L.dlco_get_rows.argtypes = [vp, C.c_int32, C.c_int32, f32p]
     L.dlco_get_index.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p]
     for name in ("dlco_step", "dlco_step_begin", "dlco_step_grad", "dlco_step_finish", "dlco_sync"):
@@ -155,12 +156,13 @@ class Context:
     """One pj-learn trainer on one GPU (thin wrapper over dlco_ctx)."""
 
     def __init__(self, F, N, B=200, mu=0.001, gamma=0.5, seed=2215, device=0, rank=0, world=1,
-                 eig_tol=None, eig_guard=None, eig_max_iter=None, shard=0):
+                 eig_tol=None, eig_guard=None, eig_max_iter=None, shard=0, strict_conv=0):
         self.L = load()
         cfg = Cfg()
         self.L.dlco_cfg_default(C.byref(cfg))
         cfg.F, cfg.N, cfg.B, cfg.mu, cfg.gamma, cfg.seed = F, N, B, mu, gamma, seed
         cfg.device, cfg.rank, cfg.world, cfg.shard = device, rank, world, shard
+        cfg.strict_conv = strict_conv
         if eig_tol is not None:
             cfg.eig_tol = eig_tol
         if eig_guard is not None:
@@ -211,10 +213,10 @@ class Context:
         assert d.ndim == 2 and d.shape[1] == self.F and q.shape == (self.N, 4)
         self._ck(self.L.dlco_set_pairs(self.h, _p(d, f32p), d.shape[0], _p(q, i32p)))
 
-    def synth_data(self, U, seed, sigma_pos, sigma_neg, noise):
+    def synth_data(self, U, seed, sigma_pos, sigma_neg, noise, scale_jitter=0.0):
         U = _f32(U)
         assert U.shape[1] == self.F
-        self._ck(self.L.dlco_synth_data(self.h, _p(U, f32p), U.shape[0], seed, sigma_pos, sigma_neg, noise))
+        self._ck(self.L.dlco_synth_data(self.h, _p(U, f32p), U.shape[0], seed, sigma_pos, sigma_neg, noise, scale_jitter))
 
     def get_rows(self, row0, n):
         out = np.empty((n, self.F), np.float32)

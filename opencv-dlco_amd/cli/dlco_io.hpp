@@ -67,6 +67,14 @@ struct H5 {
         DLCO_H5SYM(H5Sget_simple_extent_dims) DLCO_H5SYM(H5Screate_simple) DLCO_H5SYM(H5Dread) DLCO_H5SYM(H5Dwrite)
         DLCO_H5SYM(H5Dclose) DLCO_H5SYM(H5Sclose) DLCO_H5SYM(H5Lexists) DLCO_H5SYM(H5Eset_auto2)
 #undef DLCO_H5SYM
+        // hid_t is a 64-bit integer since HDF5 1.10; an older library would be called with the wrong ABI
+        auto getver = reinterpret_cast<int (*)(unsigned *, unsigned *, unsigned *)>(dlsym(h, "H5get_libversion"));
+        unsigned maj = 0, min = 0, rel = 0;
+        if (!getver || getver(&maj, &min, &rel) < 0 || maj < 1 || (maj == 1 && min < 10)) {
+            std::fprintf(stderr, "dlco_io: libhdf5 %u.%u.%u is older than 1.10 (32-bit hid_t): not used\n", maj, min, rel);
+            h = nullptr;
+            return false;
+        }
         H5open();
         H5Eset_auto2(0, nullptr, nullptr);
         hid_t *pf = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_FLOAT_g"));
@@ -190,8 +198,9 @@ struct Writer {
             const H5::hid_t s = L.H5Screate_simple(2, dims, nullptr);
             const H5::hid_t d = L.H5Dcreate2(f, name, L.native_float, s, 0, 0, 0);
             if (d < 0) throw std::runtime_error(path + ": cannot create dataset " + name);
-            if (rows != 0 && cols != 0) L.H5Dwrite(d, L.native_float, 0, 0, 0, data);
+            const int rc = (rows != 0 && cols != 0) ? L.H5Dwrite(d, L.native_float, 0, 0, 0, data) : 0;
             L.H5Dclose(d); L.H5Sclose(s);
+            if (rc < 0) throw std::runtime_error(path + ": write of dataset " + name + " failed");
         } else {
             npy_write(path + "/" + name + ".npy", data, "<f4", 4, {rows, cols});
         }

@@ -54,61 +54,58 @@ inline std::vector<float> select_pr_filters(const float *PR, int rows, int cols,
     return out;
 }
 
-// "indexes & len" array: runs of consecutive non-zero elements as (flat start index, run length)
-// pairs, src/export-opencv.cpp:236-277 (and :318-359 for W) — including its layout quirks:
-// start in lower-case hex, length in upper-case hex, a line break after every 8th pair.
-inline void write_index_array(FILE *out, const float *M, int rows, int cols)
+// Maximal runs of consecutive non-zero elements of M in flat (row-major) order.
+struct Run { long start, count; };
+inline std::vector<Run> nonzero_runs(const float *M, size_t n)
 {
-    long total = 0;
-    for (size_t e = 0; e < (size_t)rows * cols; e++) total += M[e] != 0.0f;
-    int idx = 0;
-    long start = -1, count = 0;
-    for (int r = 0; r < rows; r++) {
-        for (int c = 0; c < cols; c++) {
-            const float v = M[(size_t)r * cols + c];
-            if (v != 0.0f) {
-                total--; count++;
-                if (start == -1) start = (long)r * cols + c;
-            }
-            if (total == 0 || v == 0.0f) {
-                if (count != 0) {
-                    idx++;
-                    if (idx == 1) std::fprintf(out, "{\n ");
-                    std::fprintf(out, "0x%x,0x%X", (unsigned)start, (unsigned)count);
-                    if (total == 0) {
-                        std::fprintf(out, "\n};\n");
-                        break;
-                    } else std::fprintf(out, ",");
-                    if (idx % 8 == 0) std::fprintf(out, "\n ");
-                    start = -1; count = 0;
-                }
-            }
-        }
+    std::vector<Run> runs;
+    for (size_t e = 0; e < n;) {
+        if (M[e] == 0.0f) { e++; continue; }
+        size_t b = e;
+        while (e < n && M[e] != 0.0f) e++;
+        runs.push_back({(long)b, (long)(e - b)});
     }
+    return runs;
 }
 
-// the non-zero elements themselves, as the bit patterns of the floats, src/export-opencv.cpp:284-306
+// "indexes & len" array (src/export-opencv.cpp:236-277, and :318-359 for W): the runs as
+// (flat start index, run length) pairs — start in lower-case hex, length in upper-case hex, eight
+// pairs per line, "};" after the last one.  A matrix without non-zeros produces no bytes at all.
+// One behaviour of the reference's writer is part of the format and kept: its scan stops only the
+// current row once the last run is out, so for every row BELOW the one holding the last non-zero
+// element it emits that last pair and the closing "};" once more (never the case for a learned W,
+// whose rows are dense).
+inline void write_index_array(FILE *out, const float *M, int rows, int cols)
+{
+    const std::vector<Run> runs = nonzero_runs(M, (size_t)rows * cols);
+    if (runs.empty()) return;
+    std::fprintf(out, "{\n ");
+    for (size_t i = 0; i < runs.size(); i++) {
+        std::fprintf(out, "0x%x,0x%X", (unsigned)runs[i].start, (unsigned)runs[i].count);
+        if (i + 1 == runs.size()) break;
+        std::fprintf(out, ",");
+        if ((i + 1) % 8 == 0) std::fprintf(out, "\n ");
+    }
+    std::fprintf(out, "\n};\n");
+    const Run &last = runs.back();
+    const long last_row = (last.start + last.count - 1) / cols;
+    for (long r = last_row + 1; r < rows; r++)
+        std::fprintf(out, "0x%x,0x%X\n};\n", (unsigned)last.start, (unsigned)last.count);
+}
+
+// the non-zero elements themselves as the bit patterns of the floats, eight per line
+// (src/export-opencv.cpp:284-306); the opening brace is written even when there is no element
 inline void write_value_array(FILE *out, const float *M, int rows, int cols)
 {
-    long total = 0;
-    for (size_t e = 0; e < (size_t)rows * cols; e++) total += M[e] != 0.0f;
-    long count = 1;
-    for (int r = 0; r < rows; r++) {
-        for (int c = 0; c < cols; c++) {
-            if (r + c == 0) std::fprintf(out, "{\n ");
-            const float v = M[(size_t)r * cols + c];
-            if (v != 0.0f) {
-                uint32_t bits;
-                std::memcpy(&bits, &v, 4);
-                std::fprintf(out, "0x%08x", bits);
-                if (count == total) {
-                    std::fprintf(out, "\n};\n");
-                    break;
-                } else std::fprintf(out, ",");
-                if (count % 8 == 0) std::fprintf(out, "\n ");
-                count++;
-            }
-        }
+    std::vector<uint32_t> bits;
+    for (size_t e = 0; e < (size_t)rows * cols; e++)
+        if (M[e] != 0.0f) { uint32_t b; std::memcpy(&b, &M[e], 4); bits.push_back(b); }
+    if (rows * cols > 0) std::fprintf(out, "{\n ");
+    for (size_t i = 0; i < bits.size(); i++) {
+        std::fprintf(out, "0x%08x", bits[i]);
+        if (i + 1 == bits.size()) { std::fprintf(out, "\n};\n"); break; }
+        std::fprintf(out, ",");
+        if ((i + 1) % 8 == 0) std::fprintf(out, "\n ");
     }
 }
 

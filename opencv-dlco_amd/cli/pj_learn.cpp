@@ -116,6 +116,9 @@ int main(int argc, char **argv)
                                 e.loss_val, e.regul, e.obj, e.obj_best, e.rank, e.rank_best, ttime, e.vtime);
                 }
                 cout << std::flush;
+                if (e.nonconv > 0)            // stdout is a wire format (scraped by the reference's scripts): warn on stderr
+                    std::fprintf(stderr, "pj-learn: warning: %d of the last %u steps ended above the eigen tolerance (t = %u)\n",
+                                 e.nonconv, LogStep, e.t);
                 step = 0;
                 train_start = std::chrono::steady_clock::now();
             }

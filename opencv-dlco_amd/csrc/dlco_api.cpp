@@ -66,6 +66,7 @@ struct dlco_ctx {
     EigTracker *eig = nullptr;
     RocWork *roc = nullptr;
     int64_t nonconv_steps = 0, steps_run = 0, active_rows_sum = 0;
+    int32_t nonconv_window = 0;      // non-converged steps since the last dlco_log_step
 
     // model selection (src/pj-learn.cpp:229-232)
     double auc_best = 0.0;
@@ -262,10 +263,7 @@ void gather_dists(dlco_ctx *c, const float **pd, const float **nd)
 
 void rda_coeffs(const dlco_ctx *c, float *alpha, float *beta)
 {
-    // src/pj-learn.cpp:422: addWeighted(dfAvg, (double)t/(t+1), dLoss, 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg)
-    const unsigned t = c->t, B = (unsigned)c->B;
-    *beta = (float)((double)t / (t + 1));
-    *alpha = 1.0f / (float)(unsigned)(B * B * (t + 1));
+    dlco::rda_coeffs((uint32_t)c->B, c->t, alpha, beta);   // pair_index.hpp (64-bit denominator)
 }
 
 void step_begin(dlco_ctx *c)
@@ -342,11 +340,14 @@ void step_finish(dlco_ctx *c)
     // rows that entered this rank's SYRK this step: read back with the tracker's own synchronisation
     DLCO_HIP(hipMemcpyAsync(c->pin_k, c->k_active.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
-    if (!conv) c->nonconv_steps++;
+    if (!conv) { c->nonconv_steps++; c->nonconv_window++; }
     c->active_rows_sum += *c->pin_k;                      // update() synchronised after the copy was queued
     c->steps_run++;
     c->t++;
     c->phase = 0;
+    if (!conv && c->cfg.strict_conv)
+        throw Error(DLCO_ERR_NOCONV, "dlco_step: the eigen tracker missed its tolerance at t = " + std::to_string(c->t - 1) +
+                                     " (the step was applied; W is approximate)");
 }
 
 // One step with the dual average sharded by columns (cfg.shard): the rank projects its batch
@@ -467,7 +468,10 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const size_t FF = (size_t)c->F * c->F;
         c->dfavg.alloc(FF); c->dfavg.zero(c->stream);
         c->grad.alloc(FF);
-        const int max_rows = 1024;                               // block capacity (positive rank + guards)
+        // block capacity (positive rank + guards).  At t = 0 (W = 0, every pair violates) the positive
+        // eigenspace of -dfAvg has up to B dimensions (the negative rows), so the capacity follows the
+        // global batch; a block that fills up nevertheless is reported as non-converged.
+        const int max_rows = std::max(1024, 2 * cfg->B + 2 * c->cfg.eig_guard);
         c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
         c->eig->set_profiler(&c->prof);
         c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
@@ -580,7 +584,7 @@ int dlco_set_data_device(dlco_ctx *c, const float *dists_dev, const uint8_t *lab
 }
 
 int dlco_synth_data(dlco_ctx *c, const float *U_host, int32_t k, uint64_t seed, float sigma_pos, float sigma_neg,
-                    float noise)
+                    float noise, float scale_jitter)
 {
     if (!c || !U_host || k < 1 || k > 4096) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
@@ -589,7 +593,7 @@ int dlco_synth_data(dlco_ctx *c, const float *U_host, int32_t k, uint64_t seed, 
         DevBuf<float> U;
         U.alloc((size_t)k * c->F);
         h2d(c, U.p, U_host, (size_t)k * c->F * sizeof(float));
-        synth_rows(c->dists_own.p, c->N, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, c->stream);
+        synth_rows(c->dists_own.p, c->N, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, scale_jitter, c->stream);
         sync(c);
         c->dists = c->dists_own.p;
         c->pair_mode = false;
@@ -662,6 +666,11 @@ int dlco_dev_buffer(dlco_ctx *c, int32_t which, void **dev_ptr, size_t *bytes)
     case DLCO_BUF_GRAD: *dev_ptr = c->xgrad; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_DFAVG: *dev_ptr = c->dfavg.p; *bytes = FF; return DLCO_OK;
     case DLCO_BUF_W: *dev_ptr = c->W.p; *bytes = (size_t)c->r * c->F * sizeof(float); return DLCO_OK;
+    case DLCO_BUF_DATA:
+        if (!c->have_data) return DLCO_ERR_INVALID;
+        *dev_ptr = const_cast<float *>(c->dists);
+        *bytes = (size_t)(c->pair_mode ? c->P : c->N) * c->F * sizeof(float);
+        return DLCO_OK;
     case DLCO_BUF_GATHER:
         if (!c->shard) return DLCO_ERR_INVALID;
         *dev_ptr = c->comm.gather; *bytes = c->comm.gather_floats * sizeof(float); return DLCO_OK;
@@ -787,8 +796,13 @@ int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float
             h2d(c, c->W.p, W_host, (size_t)r * c->F * sizeof(float));
             c->r = r;
             c->eig->seed_rows(c->W.p, c->F, nullptr, r);
+            // trace(A) of the regulariser (src/pj-learn.cpp:527) for this W: trace(W^T W) = |W|_F^2
+            double tr = 0.0;
+            for (size_t i = 0; i < (size_t)r * c->F; i++) tr += (double)W_host[i] * (double)W_host[i];
+            c->traceA = tr;
         } else {
             c->r = 0;
+            c->traceA = 0.0;
         }
     });
 }
@@ -1016,6 +1030,8 @@ int dlco_log_step(dlco_ctx *c, dlco_log_entry *out)
         out->obj_best = c->obj_best; out->rank_best = c->r_best;
         out->auc_best = c->auc_best; out->fpr95_best = c->fpr95_best;
         out->vtime = std::chrono::duration<double>(t1 - t0).count();
+        out->nonconv = c->nonconv_window;
+        c->nonconv_window = 0;
     });
 }
 

@@ -205,7 +205,7 @@ void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int wo
 
 // synthetic stand-in for a *-unproj.h5 generated in HBM (bench): d = U^T z + eps, clipped
 void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
-                float noise, hipStream_t s);
+                float noise, float jitter, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // small dense eigen problems on one workgroup (kernels_eig.hip)

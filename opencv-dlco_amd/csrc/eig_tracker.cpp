@@ -475,6 +475,10 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             conv = false;
             continue;
         }
+        // a full block that cannot grow while the positive eigenspace still reaches into its guards
+        // cannot certify the rank: the reference keeps EVERY positive eigen-direction
+        // (src/pj-learn.cpp:480-484), so this is reported, never silently truncated
+        if (m_ < F_ && m_ >= cap_ && nw > m_ - std::max(2, guard_ / 2)) { conv = false; it++; break; }
         if (conv) { it++; break; }
     }
     st_.iters += it;

@@ -240,14 +240,17 @@ __device__ __forceinline__ float gauss(uint64_t key)
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
 }
 
-// row i: label 1 when i is even; d = U^T z + noise*eps, z ~ N(0, sigma^2 I_k), clipped to [-1, 1]
+// row i: label 1 when i is even; d = U^T z + noise*eps, z ~ N(0, (sigma*s_i)^2 I_k), clipped to [-1, 1].
+// s_i = exp(jitter * g_i) is a per-row log-normal scale: it makes the two classes overlap the way real
+// match / non-match distances do (FPR@95 of a few per cent instead of perfectly separable rows).
 __global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, const float *U, int k, uint64_t seed,
-                                                    float sig_pos, float sig_neg, float noise)
+                                                    float sig_pos, float sig_neg, float noise, float jitter)
 {
     extern __shared__ float z[];
     const int i = blockIdx.x;
     if (i >= N) return;
-    const float sig = (i % 2 == 0) ? sig_pos : sig_neg;
+    float sig = (i % 2 == 0) ? sig_pos : sig_neg;
+    if (jitter != 0.f) sig *= __expf(jitter * gauss(seed * 0x100000001B3ULL + ((uint64_t)i << 20) + 0x7000000000000000ULL));
     for (int q = threadIdx.x; q < k; q += blockDim.x)
         z[q] = sig * gauss(seed * 0x100000001B3ULL + ((uint64_t)i << 20) + (uint64_t)q + 0x5000000000000000ULL);
     __syncthreads();
@@ -364,10 +367,10 @@ void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const
 }
 
 void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
-                float noise, hipStream_t s)
+                float noise, float jitter, hipStream_t s)
 {
     hipLaunchKernelGGL(synth_kernel, dim3(N), dim3(256), k * sizeof(float), s, D, N, F, U, k, seed, sig_pos, sig_neg,
-                       noise);
+                       noise, jitter);
     DLCO_HIP(hipGetLastError());
 }
 

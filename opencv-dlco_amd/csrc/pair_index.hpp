@@ -60,4 +60,16 @@ struct PairIndex {
     }
 };
 
+// U1 coefficients (src/pj-learn.cpp:422): addWeighted(dfAvg, (double)t/(t+1), dLoss,
+// 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg).  The reference forms the denominator in 32-bit
+// unsigned arithmetic; with its B = 200 and t <= 50000 that never wraps.  Here B is the GLOBAL
+// batch (1600 on 8 GPUs) and would wrap at t = 1677, so the product is formed in 64 bits:
+// identical bits wherever the reference itself does not wrap.
+inline void rda_coeffs(uint32_t B, uint32_t t, float *w_dloss, float *w_dfavg)
+{
+    *w_dfavg = (float)((double)t / ((double)t + 1.0));
+    const uint64_t den = (uint64_t)B * (uint64_t)B * ((uint64_t)t + 1u);
+    *w_dloss = 1.0f / (float)den;
+}
+
 }  // namespace dlco

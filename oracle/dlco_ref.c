@@ -356,14 +356,16 @@ void dlco_ref_grad_reform_f64(const float *P, const float *Ng,
 /* U1/U2                                                                     */
 /* ------------------------------------------------------------------------- */
 /* src/pj-learn.cpp:422: addWeighted(dfAvg, (double)t/(t+1), dLoss,
- * 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg).  The beta denominator is a 32-bit
+ * 1.0f/(szBatch*szBatch*(t+1)), 0, dfAvg).  The reference's beta denominator is a 32-bit
  * unsigned product.  cv::addWeighted on CV_32F evaluates
  * src1*alpha + src2*beta + gamma with float scalars [OpenCV-src].           */
 void dlco_ref_rda_update(float *dfavg, const float *dloss,
                          unsigned t, unsigned B, int F)
 {
     double alpha_d = (double)t / (t + 1);
-    float  beta_f  = 1.0f / (float)(unsigned)(B * B * (t + 1));
+    /* 64-bit product: the same bits as the reference's 32-bit one wherever that does not
+     * wrap (B = 200: t < 107374); the GLOBAL batch of a multi-GPU run would wrap it */
+    float  beta_f  = 1.0f / (float)((unsigned long long)B * (unsigned long long)B * ((unsigned long long)t + 1ull));
     float  alpha   = (float)alpha_d, beta = beta_f;
     size_t FF = (size_t)F * F;
 #pragma omp parallel for schedule(static)
@@ -396,12 +398,12 @@ void dlco_ref_dual_to_primal(const float *dfavg, float mu, float gamma,
 /* ------------------------------------------------------------------------- */
 /* E1/E2: src/pj-learn.cpp:434-490                                           */
 /* ------------------------------------------------------------------------- */
-int dlco_ref_psd_project(float *A, int F, float *W, int *r, float *evals)
+static int psd_project_impl(float *A, int F, float *W, int *r, float *evals, int want_A)
 {
     size_t FF = (size_t)F * F;
     float *Eval = (float *)malloc(sizeof(float) * F);
     float *Evec = (float *)malloc(sizeof(float) * FF);
-    float *Bmul = (float *)malloc(sizeof(float) * FF);
+    float *Bmul = (float *)malloc(sizeof(float) * (want_A ? FF : 1));
     float *sqB  = (float *)malloc(sizeof(float) * FF);
     int rc = 0;
     if (g_ssyevr) {
@@ -426,12 +428,12 @@ int dlco_ref_psd_project(float *A, int F, float *W, int *r, float *evals)
         float sqe = sqrtf(e);
         for (int c = 0; c < F; c++) {
             float v = Evec[(size_t)c * F + q];
-            Bmul[(size_t)q * F + c] = e * v;
+            if (want_A) Bmul[(size_t)q * F + c] = e * v;
             sqB [(size_t)q * F + c] = sqe * v;
         }
     }
     /* A = Evec * Bmul (src/pj-learn.cpp:472-478)                            */
-    ref_sgemm(kNoTrans, kNoTrans, F, F, F, 1.0f, Evec, F, Bmul, F, 0.0f, A, F);
+    if (want_A) ref_sgemm(kNoTrans, kNoTrans, F, F, F, 1.0f, Evec, F, Bmul, F, 0.0f, A, F);
     /* W = rows with diagDPos != 0 (src/pj-learn.cpp:481-484)                */
     int rows = 0;
     for (int q = 0; q < F; q++) {
@@ -442,6 +444,19 @@ int dlco_ref_psd_project(float *A, int F, float *W, int *r, float *evals)
     *r = rows;
     free(Eval); free(Evec); free(Bmul); free(sqB);
     return 0;
+}
+
+int dlco_ref_psd_project(float *A, int F, float *W, int *r, float *evals)
+{
+    return psd_project_impl(A, F, W, r, evals, 1);
+}
+
+/* Same eigendecomposition and the same W (src/pj-learn.cpp:434-469,481-490) without the
+ * F^3 back-multiplication A = Evec*Bmul (:472-478); A is left untouched.  For parity tests at
+ * F = 8192, where A+ is formed as W^T W by the caller.                                      */
+int dlco_ref_psd_factor(const float *A, int F, float *W, int *r, float *evals)
+{
+    return psd_project_impl((float *)A, F, W, r, evals, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -554,6 +569,7 @@ struct dlco_ref_ctx {
     float *pd, *nd;
     int32_t *rows_pos, *rows_neg;
     int grad_order;
+    double tm[4];              /* seconds: sample+project, gradient, RDA+dual->primal, PSD projection */
 };
 
 dlco_ref_ctx *dlco_ref_create(const float *dists, const uint8_t *labels,
@@ -598,6 +614,7 @@ void dlco_ref_set_grad_order(dlco_ref_ctx *c, int order) { c->grad_order = order
 int dlco_ref_step(dlco_ref_ctx *c)
 {
     const int B = c->B, F = c->F;
+    double t0 = omp_get_wtime(), t1;
     /* sample (src/pj-learn.cpp:310-329)                                     */
     for (int k = 0; k < B; k++) {
         int ip = dlco_ref_rng_uniform(&c->rng, 0, c->n_pos_trn);
@@ -610,6 +627,7 @@ int dlco_ref_step(dlco_ref_ctx *c)
     /* distances (:332-365)                                                  */
     dlco_ref_project_sqdist(c->W, c->r, F, c->Pb, B, c->pd);
     dlco_ref_project_sqdist(c->W, c->r, F, c->Nb, B, c->nd);
+    t1 = omp_get_wtime(); c->tm[0] += t1 - t0; t0 = t1;
     /* gradient (:367-418)                                                   */
     if (c->grad_order == 0) {
         dlco_ref_grad_reforder(c->Pb, c->Nb, c->pd, c->nd, B, F, c->dloss);
@@ -619,12 +637,22 @@ int dlco_ref_step(dlco_ref_ctx *c)
         dlco_ref_grad_reform(c->Pb, c->Nb, rho, kap, B, F, c->dloss);
         free(rho); free(kap);
     }
+    t1 = omp_get_wtime(); c->tm[1] += t1 - t0; t0 = t1;
     /* RDA average, dual -> primal, PSD projection (:420-490)                */
     dlco_ref_rda_update(c->dfavg, c->dloss, c->t, (unsigned)B, F);
     dlco_ref_dual_to_primal(c->dfavg, c->mu, c->gamma, c->t, F, c->A);
+    t1 = omp_get_wtime(); c->tm[2] += t1 - t0; t0 = t1;
     int rc = dlco_ref_psd_project(c->A, F, c->W, &c->r, NULL);
+    t1 = omp_get_wtime(); c->tm[3] += t1 - t0;
     c->t++;
     return rc;
+}
+
+/* wall seconds spent since creation in: [0] sampling + P1/P2, [1] Q1 gradient, [2] U1/U2,
+ * [3] E1/E2 (ssyevr + back-multiplication)                                                  */
+void dlco_ref_get_timers(const dlco_ref_ctx *c, double out[4])
+{
+    for (int i = 0; i < 4; i++) out[i] = c->tm[i];
 }
 
 void dlco_ref_get_batch_ids(const dlco_ref_ctx *c, int32_t *pos_rows, int32_t *neg_rows)

@@ -102,6 +102,10 @@ void dlco_ref_dual_to_primal(const float *dfavg, float mu, float gamma,
  * quirk, src/pj-learn.cpp:489-490).  evals (may be NULL) receives all F
  * eigenvalues ascending.  Returns 0 on success.                            */
 int dlco_ref_psd_project(float *A, int F, float *W, int *r, float *evals);
+/* The same ssyevr call and the same W (src/pj-learn.cpp:434-469,481-490) without the F^3
+ * back-multiplication A = Evec*Bmul (:472-478); A is not modified.  Used by the F = 8192
+ * parity tests, which form A+ = W^T W themselves.                                          */
+int dlco_ref_psd_factor(const float *A, int F, float *W, int *r, float *evals);
 
 /* ---- H1 (src/kernelop-opencv.cu:49-66 + src/pj-learn.cpp:520) ------------
  * per-row sequential fp32 sum of max(pos_i + 1 - neg_j, 0); rows summed in
@@ -131,6 +135,8 @@ void dlco_ref_set_grad_order(dlco_ref_ctx *c, int order);
 /* one iteration of the loop at src/pj-learn.cpp:305-490 (uses and then
  * increments the context's t).  Returns 0 on success.                      */
 int  dlco_ref_step(dlco_ref_ctx *c);
+/* wall seconds since creation: [0] sampling + P1/P2, [1] Q1, [2] U1/U2, [3] E1/E2 */
+void dlco_ref_get_timers(const dlco_ref_ctx *c, double out[4]);
 /* teacher forcing hooks                                                     */
 void dlco_ref_get_batch_ids(const dlco_ref_ctx *c, int32_t *pos_rows, int32_t *neg_rows);
 void dlco_ref_get_batch_dists(const dlco_ref_ctx *c, float *pd, float *nd);

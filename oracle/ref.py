@@ -80,6 +80,9 @@ def lib():
     L.dlco_ref_dual_to_primal.argtypes = [c_f32p, C.c_float, C.c_float, C.c_uint, C.c_int, c_f32p]
     L.dlco_ref_psd_project.argtypes = [c_f32p, C.c_int, c_f32p, C.POINTER(C.c_int), c_f32p]
     L.dlco_ref_psd_project.restype = C.c_int
+    L.dlco_ref_psd_factor.argtypes = [c_f32p, C.c_int, c_f32p, C.POINTER(C.c_int), c_f32p]
+    L.dlco_ref_psd_factor.restype = C.c_int
+    L.dlco_ref_get_timers.argtypes = [C.c_void_p, c_f64p]
     L.dlco_ref_hinge_sum.argtypes = [c_f32p, C.c_int, c_f32p, C.c_int]
     L.dlco_ref_hinge_sum.restype = C.c_double
     L.dlco_ref_trace.argtypes = [c_f32p, C.c_int]
@@ -238,6 +241,19 @@ def psd_project(A):
     return A, W[:r.value].copy(), ev
 
 
+def psd_factor(A):
+    """E1 + the W half of E2 (ssyevr, W = rows sqrt(e)*v ascending) without the F^3 product: (W[r,F], evals[F])"""
+    A = np.ascontiguousarray(A, np.float32)
+    F = A.shape[0]
+    W = np.empty((F, F), np.float32)
+    ev = np.empty(F, np.float32)
+    r = C.c_int()
+    rc = lib().dlco_ref_psd_factor(_p(A, c_f32p), F, _p(W, c_f32p), C.byref(r), _p(ev, c_f32p))
+    if rc != 0:
+        raise RuntimeError("dlco_ref_psd_factor failed: %d" % rc)
+    return W[:r.value].copy(), ev
+
+
 def hinge_sum(pos, neg):
     pos = np.ascontiguousarray(pos, np.float32)
     neg = np.ascontiguousarray(neg, np.float32)
@@ -286,6 +302,12 @@ class Trainer:
         rc = lib().dlco_ref_step(self._h)
         if rc != 0:
             raise RuntimeError("dlco_ref_step failed: %d" % rc)
+
+    def timers(self):
+        """seconds since creation: sample+project, gradient, RDA + dual->primal, PSD projection"""
+        out = np.zeros(4, np.float64)
+        lib().dlco_ref_get_timers(self._h, _p(out, c_f64p))
+        return dict(project=out[0], grad=out[1], rda=out[2], eig=out[3])
 
     def batch_ids(self):
         p = np.empty(self.B, np.int32)

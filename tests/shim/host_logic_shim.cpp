@@ -32,6 +32,8 @@ void shim_sample(uint64_t seed, int n_pos_trn, int n_neg_trn, int B, int steps, 
 
 int shim_split(uint64_t n) { return dlco::PairIndex::split((size_t)n); }
 
+void shim_rda_coeffs(uint32_t B, uint32_t t, float *w_dloss, float *w_dfavg) { dlco::rda_coeffs(B, t, w_dloss, w_dfavg); }
+
 uint32_t shim_rng_next(uint64_t *state)
 {
     dlco::CvRng r(*state);

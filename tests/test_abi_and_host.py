@@ -70,6 +70,7 @@ def shim(tmp_path_factory):
     L.shim_split.argtypes = [C.c_uint64]
     L.shim_rng_next.argtypes = [C.POINTER(C.c_uint64)]
     L.shim_rng_next.restype = C.c_uint32
+    L.shim_rda_coeffs.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return L
 
 
@@ -106,3 +107,31 @@ def test_product_sampler_and_rng_bit_exact_vs_oracle(shim, ref):
     r2 = ref.Rng(0xFFFFFFFF)
     assert [shim.shim_rng_next(C.byref(st)) for _ in range(100)] == [r2.next() for _ in range(100)]
     assert [shim.shim_split(n) for n in (250000, 1999, 7, 0)] == [ref.split(n) for n in (250000, 1999, 7, 0)]
+
+
+def test_rda_coefficients_do_not_wrap_at_multi_gpu_batch_sizes(shim, ref):
+    """src/pj-learn.cpp:422 forms szBatch*szBatch*(t+1) in 32-bit unsigned arithmetic; with the
+    GLOBAL batch of an 8-GPU run (B = 1600) that product passes 2^32 at t = 1677.  Product and
+    oracle form it in 64 bits: same bits as the reference wherever the reference does not wrap,
+    monotonically decreasing beyond."""
+    def coeffs(B, t):
+        a, b = C.c_float(), C.c_float()
+        shim.shim_rda_coeffs(B, t, C.byref(a), C.byref(b))
+        return a.value, b.value
+    # the reference's own range: identical to its 32-bit expression
+    for B, t in ((200, 0), (200, 1), (200, 49999), (200, 50000), (50, 7), (1, 0)):
+        a, b = coeffs(B, t)
+        assert a == float(np.float32(1.0) / np.float32(np.uint32(B * B * (t + 1))))
+        assert b == float(np.float32(np.float64(t) / np.float64(t + 1)))
+    # across the old wrap points: strictly decreasing, never inf / nan
+    for B, ts in ((1600, range(1670, 1685)), (400, range(26840, 26850)), (294, range(49680, 49700))):
+        al = [coeffs(B, t)[0] for t in ts]
+        assert all(np.isfinite(al)) and all(x > y for x, y in zip(al, al[1:]))
+        assert abs(al[0] * (B * B * (ts[0] + 1)) - 1.0) < 1e-6
+    # the oracle applies the same coefficients
+    df = np.full((2, 2), 3.0, np.float32)
+    dl = np.full((2, 2), 5.0e9, np.float32)
+    for B, t in ((1600, 1676), (1600, 1677), (1600, 1678), (200, 11)):
+        a, b = coeffs(B, t)
+        want = df * np.float32(b) + dl * np.float32(a)
+        assert np.array_equal(ref.rda_update(df, dl, t, B), want)

@@ -317,6 +317,16 @@ def test_validation_and_stats(dlco, ref):
     ctx.set_state(st["t"], st["dfavg"], W)
     lo_ref, rg_ref = tr.validate()
     dim_ref, f95_ref, auc_ref = tr.stats()
+    # T1/H1/H2 on the SAME model: the oracle's W in the GPU context (set_state takes trace(A) = |W|_F^2)
+    ctx.set_state(st["t"], st["dfavg"], st["W"])
+    lo_same, rg_same, rk_same = ctx.validate()
+    assert rk_same == st["W"].shape[0]
+    assert abs(lo_same - lo_ref) <= TOL_LOSS * max(lo_ref, 1e-12)        # 50k^2-term hinge sum, same W: 1e-5 relative
+    assert abs(rg_same - rg_ref) <= 1e-5 * max(rg_ref, 1e-12)            # mu * trace(A)
+    # and on the GPU's own re-derived W (tracker tolerance on A+ carries over to the objective)
+    ctx.set_state(st["t"], st["dfavg"], W)
+    lo_gpu, rg_gpu, _ = ctx.validate()
+    assert abs(lo_gpu - lo_ref) <= 1e-3 * max(lo_ref, 1e-12) and abs(rg_gpu - rg_ref) <= 1e-3 * max(rg_ref, 1e-12)
     dim, f95, auc = ctx.stats(W)
     assert abs(dim - dim_ref) <= 1
     assert abs(f95 - f95_ref) <= 1e-3          # +-0.1 % absolute, the metric's stated band
@@ -508,3 +518,72 @@ def test_config0_trajectory_band(dlco, ref):
     assert ctx.counters()["nonconverged"] == 0
     ctx.close()
     tr.close()
+
+
+def test_log_step_branches_best_step_saved(dlco, ref):
+    """The model-selection block, src/pj-learn.cpp:527-580: "Best:" iff Loss+Regul improves,
+    "[saved]" iff additionally AUC_Best <= AUC and FPR95_Best >= FPR95, else "Step:".  A scripted
+    sequence of models visits every branch; the flags must follow the rule applied to the entry's
+    own numbers and the saved W / A must be those of the last saved entry."""
+    N, F, B = 6000, 64, 50
+    D, L = synth(N, F, k=10, seed=21, sp=0.7, noise=0.2)
+    mu, gamma = 0.004, 0.5
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    ctx.steps(60)
+    W = ctx.W()
+    df = ctx.dfavg()
+    assert W.shape[0] >= 4
+    inflated = (4.0 * W).astype(np.float32)          # same ranking (x16 distances, exact), 16x the regulariser
+    fewer = W[:-1].copy()                               # without the top direction: worse ROC, objective below `inflated`
+    script = [("inflated", inflated), ("fewer", fewer), ("inflated again", inflated), ("full", W)]
+    obj_best, auc_best, f_best = np.inf, 0.0, np.inf
+    seen, last_saved = [], None
+    for i, (name, Wi) in enumerate(script):
+        ctx.set_state(61 + i, df, Wi)
+        e = ctx.log_step()
+        assert e.t == 60 + i and e.rank == Wi.shape[0]
+        assert abs(e.obj - (e.loss_val + e.regul)) <= 1e-6 * max(e.obj, 1.0)
+        is_best = bool(e.obj < obj_best)
+        assert bool(e.is_best) == is_best, name
+        if is_best:
+            obj_best = e.obj
+            assert e.dim == Wi.shape[0]
+            saved = auc_best <= e.auc and f_best >= e.fpr95
+            assert bool(e.saved) == saved, name
+            if saved:
+                auc_best, f_best = e.auc, e.fpr95
+                last_saved = Wi
+        else:
+            assert e.saved == 0
+        assert e.obj_best == np.float32(obj_best) and e.auc_best == auc_best and e.fpr95_best == np.float32(f_best)
+        seen.append((int(e.is_best), int(e.saved)))
+    # every branch was visited: Best+saved, Best without [saved], Step
+    assert (1, 1) in seen and (1, 0) in seen and (0, 0) in seen, seen
+    Ws, As = ctx.saved()
+    assert np.array_equal(Ws, last_saved)
+    assert relmax(Ws.T.astype(np.float64) @ Ws.astype(np.float64), As) <= 1e-5
+    ctx.close()
+
+
+def test_strict_conv_surfaces_a_missed_tolerance(dlco):
+    """cfg.strict_conv: a step whose tracker stops at its iteration cap returns DLCO_ERR_NOCONV
+    (the default only counts it: counters()['nonconverged'], log entry .nonconv)."""
+    N, F, B = 3000, 256, 40
+    D, L = synth(N, F, k=60, seed=5, sp=0.9, noise=0.3)
+    # an unreachable tolerance with a single filter + Rayleigh-Ritz pass per step
+    lax = dlco.Context(F, N, B=B, mu=0.0005, gamma=0.5, eig_tol=1e-9, eig_max_iter=1)
+    lax.set_data(D, L)
+    lax.steps(12)
+    n_missed = lax.counters()["nonconverged"]
+    e = lax.log_step()
+    assert n_missed > 0 and e.nonconv == n_missed
+    assert lax.log_step().nonconv == 0                     # the window restarts at every log step
+    lax.close()
+    strict = dlco.Context(F, N, B=B, mu=0.0005, gamma=0.5, eig_tol=1e-9, eig_max_iter=1, strict_conv=1)
+    strict.set_data(D, L)
+    with pytest.raises(dlco.DlcoError) as err:
+        strict.steps(12)
+    assert err.value.code == dlco.ERR_NOCONV
+    assert strict.t() >= 1                                  # the step itself was applied
+    strict.close()

@@ -1,0 +1,104 @@
+"""Row L1 of the hot-path table: the HDF5 side of the command-line tools (cli/dlco_io.hpp).
+
+The reference reads "Distance" f32 [N,F] and "Label" u8 [N,1] in 128-row hyperslabs
+(src/pj-learn.cpp:173-212) from a file its producer writes chunked {128,1} with gzip level 9
+(src/comp-uprjdists.cpp:254,289-290), and writes "W" / "A" (src/pj-learn.cpp:592-597).
+h5py is not available, so the files are written / read through tests/shim/io_shim.cpp (the
+product's own reader + libhdf5 via dlopen)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import golden, relmax, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_H5 = "/root/reference/workspace/pj-learn/liberty-liberty-0.035-0.250-pr#7-0.0010-0.100-pj.h5"
+f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def io(tmp_path_factory):
+    out = tmp_path_factory.mktemp("ioshim") / "libioshim.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(out),
+                           os.path.join(ROOT, "tests", "shim", "io_shim.cpp"), "-ldl"])
+    L = C.CDLL(str(out))
+    L.shim_read_f32.argtypes = [C.c_char_p, C.c_char_p, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.shim_write_unproj.argtypes = [C.c_char_p, f32p, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    if not L.shim_hdf5_available():
+        pytest.skip("no libhdf5 >= 1.10 on this machine")
+    return L
+
+
+def read_f32(io, path, name, cap):
+    out = np.empty(cap, np.float32)
+    sh = (C.c_size_t * 4)()
+    nd = io.shim_read_f32(path.encode(), name.encode(), out.ctypes.data_as(f32p), cap, sh)
+    assert nd >= 0, "read of %s failed" % name
+    shape = tuple(sh[i] for i in range(nd))
+    return out[:int(np.prod(shape))].reshape(shape)
+
+
+def write_unproj(io, path, D, L, chunk=(128, 1), gzip=9):
+    D = np.ascontiguousarray(D, np.float32)
+    L = np.ascontiguousarray(L, np.uint8).ravel()
+    rc = io.shim_write_unproj(path.encode(), D.ctypes.data_as(f32p), L.ctypes.data_as(u8p), D.shape[0], D.shape[1],
+                              chunk[0], chunk[1], gzip)
+    assert rc == 0, rc
+
+
+def test_reads_the_reference_result_file(io):
+    """/W and /A of a result file the reference ships, read through the product's reader, against
+    the golden copy of the same file (tests/golden/ref_results.npz, made by make_golden.py)."""
+    if not os.path.exists(REF_H5):
+        pytest.skip("/root/reference is not present on this machine")
+    z = golden("ref_results.npz")
+    assert str(z["r0_name"]) in REF_H5
+    W = read_f32(io, REF_H5, "W", 544 * 544)
+    A = read_f32(io, REF_H5, "A", 544 * 544)
+    assert W.shape == (67, 544) and A.shape == (544, 544)
+    assert np.array_equal(W, z["r0_W"]) and np.array_equal(A, z["r0_A"])
+    assert relmax(W.T.astype(np.float64) @ W.astype(np.float64), A) <= 1e-6          # A == W^T W
+
+
+@pytest.mark.parametrize("chunk,gzip", [((128, 1), 9), ((64, 16), 0), ((4096, 4096), 4)])
+def test_chunked_deflate_input_round_trip(io, tmp_path, chunk, gzip):
+    """The producer's layout ({128,1} chunks, gzip 9) and two others: every byte comes back."""
+    N, F = 700, 48
+    D, L = synth(N, F, k=6, seed=3)
+    path = str(tmp_path / "x-unproj.h5")
+    write_unproj(io, path, D, L, chunk, gzip)
+    got = read_f32(io, path, "Distance", N * F)
+    assert got.shape == (N, F) and np.array_equal(got, D)
+
+
+@pytest.mark.gpu
+def test_pj_learn_trains_from_a_producer_style_h5_file(io, tmp_path):
+    """pj-learn on an HDF5 input written like comp-uprjdists writes it, against the same run from
+    the .npy directory: identical stdout (up to the timing fields) and identical W / A."""
+    cli = os.path.join(ROOT, "opencv-dlco_amd", "cli")
+    subprocess.check_call(["make", "-s", "-C", cli])
+    pj = os.path.join(cli, "pj-learn")
+    N, F = 4000, 64
+    D, L = synth(N, F, k=10, seed=41, sp=0.7, noise=0.2)
+    h5 = str(tmp_path / "liberty-unproj.h5")
+    write_unproj(io, h5, D, L.reshape(-1, 1), (128, 1), 9)
+    npy = tmp_path / "unproj_npy"
+    npy.mkdir()
+    np.save(npy / "Distance.npy", D)
+    np.save(npy / "Label.npy", L.reshape(-1, 1))
+    outs = []
+    for src, dst in ((h5, str(tmp_path / "out.h5")), (str(npy), str(tmp_path / "out_npy"))):
+        p = subprocess.run([pj, src, dst, "-mu", "0.004", "-iters", "200", "-batch", "50"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        outs.append(p.stdout)
+    import re
+    cut = lambda s: [re.sub(r"Ttime: \S+ Vtime: \S+", "", l) for l in s.splitlines()]
+    assert cut(outs[0]) == cut(outs[1])
+    assert "Load Distances: 4000 x 64" in outs[0]
+    W1 = read_f32(io, str(tmp_path / "out.h5"), "W", F * F)
+    A1 = read_f32(io, str(tmp_path / "out.h5"), "A", F * F)
+    assert np.array_equal(W1, np.load(tmp_path / "out_npy" / "W.npy")) and np.array_equal(A1, np.load(tmp_path / "out_npy" / "A.npy"))
+    assert W1.shape[1] == F and A1.shape == (F, F)
