@@ -50,11 +50,12 @@ PEAK_HBM_TBS = 8.0                # same guide: HBM3E spec peak (6.29 TB/s measu
 # workspace/pj-learn/logging/liberty-liberty-0.035-0.250-pr#7-0.0010-0.100-pj.log:23-24,423-424).
 # tests/test_full_width_gpu.py compares exactly these workloads with the oracle's ssyevr.
 WORKLOADS = {
-    "c2": dict(name="configs[1] Liberty-shaped, rank ~64", F=8192, N=500000, batch=200, mu=0.002, gamma=0.5,
-               latent=96, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.4, seed=2216,
+    # tools/sweep_synth.py picked these (gpurun_out/sweep2.log): rank 64 / FPR95 6.1 % and rank 127 / FPR95 5.6 % at step 520
+    "c2": dict(name="configs[1] Liberty-shaped, rank ~64", F=8192, N=500000, batch=200, mu=0.0025, gamma=0.5,
+               latent=96, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
                rank_band=(48, 88), fpr95_band=(0.02, 0.15)),
-    "c3": dict(name="configs[2] NotreDame-shaped, rank ~128", F=8192, N=500000, batch=200, mu=0.0007, gamma=0.5,
-               latent=192, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.4, seed=2217,
+    "c3": dict(name="configs[2] NotreDame-shaped, rank ~128", F=8192, N=500000, batch=200, mu=0.001, gamma=0.5,
+               latent=192, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
                rank_band=(100, 160), fpr95_band=(0.02, 0.15)),
 }
 

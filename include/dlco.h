@@ -161,6 +161,13 @@ int dlco_set_allgather(dlco_ctx *ctx, dlco_allgather_fn fn, void *user);
  * over the callback; dlco_comm_destroy (or dlco_ctx_destroy) releases it. */
 int dlco_comm_unique_id(void *out_id, size_t cap, const char *rccl_path);
 int dlco_comm_init(dlco_ctx *ctx, const void *id, size_t id_bytes, const char *rccl_path);
+/* Fallback transport for ranks that are processes of one node when RCCL cannot be used (no librccl, or
+ * several ranks sharing one GPU, which RCCL refuses): the all-gathers go through the POSIX shared-memory
+ * segment `shm_name` (device -> host -> device, barriers on counters inside the segment).  Every rank
+ * calls it (a collective); the segment must not exist beforehand or be all zeros, and is unlinked once
+ * every rank has attached.  Correct and deterministic but host-staged: a test / fallback path, an RCCL
+ * communicator takes precedence. */
+int dlco_comm_init_host(dlco_ctx *ctx, const char *shm_name);
 int dlco_comm_destroy(dlco_ctx *ctx);
 /* The HIP stream the context launches on (as void*), so callers can order collectives. */
 int dlco_stream(dlco_ctx *ctx, void **stream);

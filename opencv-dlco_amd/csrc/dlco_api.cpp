@@ -6,6 +6,7 @@
 #include "eig_tracker.hpp"
 #include "pair_index.hpp"
 #include "rccl_comm.hpp"
+#include "host_comm.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -85,6 +86,7 @@ struct dlco_ctx {
     dlco_allgather_fn ag_fn = nullptr;
     void *ag_user = nullptr;
     RcclComm *rccl = nullptr;        // direct RCCL communicator (dlco_comm_init); takes precedence over the callback
+    HostComm *hostcomm = nullptr;    // host-staged shared-memory fallback (dlco_comm_init_host)
 };
 
 namespace {
@@ -116,6 +118,11 @@ void allgather(dlco_ctx *c, int32_t buffer_id, size_t bytes_per_rank)
     if (c->rccl) {                                            // RCCL over xGMI, on the library's own stream
         void *buf = buffer_id == DLCO_BUF_DIST ? static_cast<void *>(c->xdist) : static_cast<void *>(c->comm.gather);
         c->rccl->allgather_inplace(buf, bytes_per_rank, c->stream);
+        return;
+    }
+    if (c->hostcomm) {                                        // fallback: through host shared memory
+        void *buf = buffer_id == DLCO_BUF_DIST ? static_cast<void *>(c->xdist) : static_cast<void *>(c->comm.gather);
+        c->hostcomm->allgather_inplace(buf, bytes_per_rank, c->stream);
         return;
     }
     DLCO_CHECK(c->ag_fn != nullptr, DLCO_ERR_INVALID, "sharded step: no all-gather callback (dlco_set_allgather)");
@@ -516,6 +523,7 @@ void dlco_ctx_destroy(dlco_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->eig;
     delete c->rccl;
+    delete c->hostcomm;
     if (c->roc) roc_work_destroy(c->roc);
     if (c->pin_ids) (void)hipHostFree(c->pin_ids);
     if (c->pin_k) (void)hipHostFree(c->pin_k);
@@ -733,10 +741,24 @@ int dlco_comm_init(dlco_ctx *c, const void *id, size_t id_bytes, const char *rcc
     });
 }
 
+int dlco_comm_init_host(dlco_ctx *c, const char *shm_name)
+{
+    if (!c || !shm_name || !*shm_name) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->shard, DLCO_ERR_INVALID, "dlco_comm_init_host: only a sharded context (cfg.shard) exchanges through the library");
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_comm_init_host: step in flight");
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        delete c->hostcomm;
+        c->hostcomm = nullptr;
+        const size_t slot = std::max((size_t)2 * c->Bl * sizeof(float), c->comm.gather_floats * sizeof(float) / c->cfg.world);
+        c->hostcomm = new HostComm(shm_name, c->cfg.rank, c->cfg.world, slot);
+    });
+}
+
 int dlco_comm_destroy(dlco_ctx *c)
 {
     if (!c) return DLCO_ERR_INVALID;
-    return guarded(c, [&] { sync(c); delete c->rccl; c->rccl = nullptr; });
+    return guarded(c, [&] { sync(c); delete c->rccl; c->rccl = nullptr; delete c->hostcomm; c->hostcomm = nullptr; });
 }
 
 int dlco_sync(dlco_ctx *c) { return c ? guarded(c, [&] { sync(c); }) : DLCO_ERR_INVALID; }

@@ -233,6 +233,322 @@ __global__ __launch_bounds__(JT) void jacobi_gmem_kernel(const float *T, long ld
     jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos);
 }
 
+// ---- n <= 128: one column pair per 16 lanes ------------------------------------------------------
+// Same method and the same arithmetic per rotation as jacobi_body, organised for the length of a
+// round on one CU (the eigen tracker calls this once per step with n ~ 96 and every round is a
+// workgroup barrier): 16 lanes per pair on up to 16 waves, so a lane carries n/16 entries of each
+// column instead of n/8 and the whole round's vector work issues in a third of the slots; the
+// round-robin schedule is a table in LDS (one 2-byte read instead of the modulo arithmetic);
+// 8-byte LDS accesses at a stride of 16 lanes, no ownership masks (columns are padded with zeros
+// to a whole number of chunks, which rotations keep zero); one barrier per round.
+constexpr int J16_MAX_N = 128;
+constexpr int J16_LP = 16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_f<0x128>(v);    // row_ror:8
+    v += dpp_f<0x124>(v);    // row_ror:4
+    v += dpp_f<0x122>(v);    // row_ror:2
+    v += dpp_f<0x121>(v);    // row_ror:1
+    return v;
+}
+
+inline int j16_chunks(int n) { return (n + 31) / 32; }                       // 8-byte chunks per lane and column
+inline int j16_ldc(int n) { const int e = j16_chunks(n); return 32 * e + ((e & 1) ? 0 : 32); }   // = 32 mod 64: two pairs of a
+                                                                             // 32-lane group mostly hit different banks
+inline int j16_threads(int n) { const int half = (n + 1) / 2; return ((half * J16_LP + 63) / 64) * 64; }
+inline size_t j16_lds_bytes(int n)
+{
+    const int ne = n + (n & 1);
+    return ((size_t)n * j16_ldc(n) + 136 + 24) * sizeof(float) + (size_t)(ne - 1) * (ne / 2) * sizeof(uint16_t) + 16;
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void jacobi16_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
+                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos)
+{
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    float *G = sh;                                   // [n][ldc], column j at G + j*ldc
+    float *nrm = G + (size_t)n * ldc;                // [136]
+    float *red = nrm + 136;                          // [24]
+    uint16_t *sched = reinterpret_cast<uint16_t *>(red + 24);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+
+    // ---- shift: sigma = 1.01 * max_i sum_j |T_ij| + tiny  (Gershgorin) ------------------------
+    float rmax = 0.f;
+    for (int i = wave; i < n; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += fabsf(T[(long)i * ldt + j]);
+        s = wsum(s);
+        rmax = fmaxf(rmax, s);
+    }
+    if (lane == 0) red[wave] = rmax;
+    // ---- the schedule: round r, slot k -> (p, q), p < q; 0xFFFF = bye ---------------------------------
+    const int ne = n + (n & 1), half = ne / 2;
+    for (int e = tid; e < (ne - 1) * half; e += nthr) {
+        const int r = e / half, k = e % half;
+        int p, q;
+        if (k == 0) { p = ne - 1; q = r; }
+        else {
+            p = r + k; if (p >= ne - 1) p -= ne - 1;
+            q = r - k; if (q < 0) q += ne - 1;
+        }
+        if (p > q) { const int t = p; p = q; q = t; }
+        sched[e] = (p < n && q < n) ? (uint16_t)(p | (q << 8)) : (uint16_t)0xFFFF;
+    }
+    __syncthreads();
+    float sigma = 0.f;
+    for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
+    sigma = 1.01f * sigma + 1e-30f;
+
+    // ---- init: G = sym(T) + sigma I, zero padding ---------------------------------------------------
+    for (int e = tid; e < n * ldc; e += nthr) {
+        const int j = e / ldc, i = e % ldc;
+        float v = 0.f;
+        if (i < n) v = 0.5f * (T[(long)i * ldt + j] + T[(long)j * ldt + i]) + (i == j ? sigma : 0.f);
+        G[e] = v;
+    }
+    __syncthreads();
+
+    const float tol = 3e-6f;
+    const int grp = tid / J16_LP, sub = tid % J16_LP;
+    const int ngrp = nthr / J16_LP;
+    const bool has_slot = grp < half;
+    int sweep = 0;
+    for (; sweep < 40; sweep++) {
+        // exact squared column norms at the start of the sweep
+        for (int j = grp; j < n; j += ngrp) {
+            const f32x2 *gj = reinterpret_cast<const f32x2 *>(G + (long)j * ldc) + sub;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) { const f32x2 x = gj[16 * e]; s += x[0] * x[0] + x[1] * x[1]; }
+            s = row16_sum(s);
+            if (sub == 0) nrm[j] = s;
+        }
+        __syncthreads();
+        float off_max = 0.f;
+        for (int r = 0; r < ne - 1; r++) {
+            const unsigned pq = has_slot ? sched[r * half + grp] : 0xFFFFu;
+            const bool live = pq != 0xFFFFu;                 // uniform over the 16 lanes of the pair
+            const int p = live ? (int)(pq & 0xFF) : 0, q = live ? (int)(pq >> 8) : 0;
+            f32x2 *gp = reinterpret_cast<f32x2 *>(G + (long)p * ldc) + sub;
+            f32x2 *gq = reinterpret_cast<f32x2 *>(G + (long)q * ldc) + sub;
+            const float a = nrm[p], b = nrm[q];
+            f32x2 x[E], y[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) { x[e] = gp[16 * e]; y[e] = gq[16 * e]; }
+            float c = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) c += x[e][0] * y[e][0] + x[e][1] * y[e][1];
+            c = row16_sum(c);
+            const float ab = a * b;
+            const float off = (live && ab > 0.f) ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
+            off_max = fmaxf(off_max, off);
+            if (off > tol) {
+                float t, cs, sn;
+                rotation(a, b, c, t, cs, sn);
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    gp[16 * e] = cs * x[e] - sn * y[e];
+                    gq[16 * e] = sn * x[e] + cs * y[e];
+                }
+                if (sub == 0) { nrm[p] = a - t * c; nrm[q] = b + t * c; }
+            }
+            __syncthreads();
+        }
+        off_max = wmax(off_max);
+        if (lane == 0) red[wave] = off_max;
+        __syncthreads();
+        float m = 0.f;
+        for (int w = 0; w < nw; w++) m = fmaxf(m, red[w]);
+        __syncthreads();
+        if (m <= stop_cos) { sweep++; break; }               // see jacobi_body for why no verification sweep follows
+    }
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+
+    // ---- eigenvalues lambda_j = |g_j| - sigma, eigenvectors v_j = g_j / |g_j|, sorted descending ----
+    float *lam = scratch, *inv = scratch + n;
+    int *rank = reinterpret_cast<int *>(scratch + 2 * n);
+    for (int j = wave; j < n; j += nw) {
+        float d = 0.f;
+        for (int i = lane; i < n; i += 64) { const float v = G[(long)j * ldc + i]; d += v * v; }
+        d = wsum(d);
+        if (lane == 0) { const float nr = sqrtf(d); lam[j] = nr - sigma; inv[j] = nr > 0.f ? 1.f / nr : 0.f; }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nthr) {
+        const float me = lam[j];
+        int rk = 0;
+        for (int k = 0; k < n; k++) {
+            const float o = lam[k];
+            rk += (o > me || (o == me && k < j)) ? 1 : 0;
+        }
+        rank[j] = rk;
+        evals[rk] = me;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nthr) {
+        const int j = e / n, i = e % n;
+        Vout[(long)i * ldv + rank[j]] = G[(long)j * ldc + i] * inv[j];
+    }
+}
+
+// ---- n <= 128, columns travel: every address of a round is static ------------------------------------
+// The round-robin tournament as a fixed permutation of SEATS: pair k always works on seat k (two column
+// slots, "top" and "bottom") and always sends its two rotated columns to the same two destination slots
+// (top_k -> top_k+1, bottom_k -> bottom_k-1, with top_0 fixed and the two turn-arounds), so that after
+// ne-1 rounds every column has met every other one and is back where it started.  Two LDS images are
+// used in turn (read one, write the other): a round is
+//     barrier -> 6 static 8-byte reads per column -> dot product (16-lane DPP sum) -> rotation ->
+//     6 static 8-byte writes per column
+// with no schedule lookup, no address arithmetic and no separate norm vector (a column's squared norm
+// rides in its slot, after the padding).  Same rotation arithmetic and stopping rule as jacobi_body.
+inline int jseat_ldc(int n) { return 32 * ((n + 31) / 32) + 16; }    // 16-byte aligned, consecutive seats 32 banks apart
+inline size_t jseat_lds_bytes(int n) { const int ne = n + (n & 1); return ((size_t)2 * ne * jseat_ldc(n) + 32) * sizeof(float); }
+
+template <int E>
+__global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
+                                                           float *scratch, int *sweeps_out, float stop_cos)
+{
+    constexpr int LDC = 32 * E + 16;
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int ne = n + (n & 1), h = ne / 2;
+    float *buf0 = sh, *buf1 = sh + (size_t)ne * LDC, *red = buf1 + (size_t)ne * LDC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+
+    // ---- shift: sigma = 1.01 * max_i sum_j |T_ij| + tiny  (Gershgorin) ------------------------
+    float rmax = 0.f;
+    for (int i = wave; i < n; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += fabsf(T[(long)i * ldt + j]);
+        s = wsum(s);
+        rmax = fmaxf(rmax, s);
+    }
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    float sigma = 0.f;
+    for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
+    sigma = 1.01f * sigma + 1e-30f;
+    // ---- column j of G = sym(T) + sigma I starts in slot j; slot n (odd n) is a zero column (the bye) ---
+    for (int e = tid; e < ne * LDC; e += nthr) {
+        const int j = e / LDC, i = e % LDC;
+        float v = 0.f;
+        if (i < n && j < n) v = 0.5f * (T[(long)i * ldt + j] + T[(long)j * ldt + i]) + (i == j ? sigma : 0.f);
+        buf0[e] = v;
+    }
+    __syncthreads();
+
+    const float tol = 3e-6f;
+    const int grp = tid / J16_LP, sub = tid % J16_LP;
+    const bool seated = grp < h;
+    // destination slots of this seat's two columns (static)
+    int dtop = 2 * grp, dbot = 2 * grp + 1;
+    if (h > 1) {
+        dtop = grp == 0 ? 0 : (grp < h - 1 ? 2 * (grp + 1) : 2 * (h - 1) + 1);
+        dbot = grp == 0 ? 2 : 2 * (grp - 1) + 1;
+    }
+    const int src_off = (seated ? 2 * grp : 0) * LDC + 2 * sub;
+    const int dtop_off = (seated ? dtop : 0) * LDC + 2 * sub, dbot_off = (seated ? dbot : 0) * LDC + 2 * sub;
+    int it = 0, sweep = 0;
+    for (; sweep < 40; sweep++) {
+        float off_max = 0.f;
+        for (int r = 0; r < ne - 1; r++, it++) {
+            const float *cur = (it & 1) ? buf1 : buf0;
+            float *nxt = (it & 1) ? buf0 : buf1;
+            if (seated) {
+                const float *st = cur + src_off, *sb = st + LDC;
+                f32x2 x[E], y[E];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    x[e] = *reinterpret_cast<const f32x2 *>(st + 32 * e);
+                    y[e] = *reinterpret_cast<const f32x2 *>(sb + 32 * e);
+                }
+                float a = st[32 * E - 2 * sub], b = sb[32 * E - 2 * sub];      // the norms ride behind the padding
+                float c = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; e++) c += x[e][0] * y[e][0] + x[e][1] * y[e][1];
+                c = row16_sum(c);
+                if (r == 0) {                                        // exact squared norms at the start of a sweep
+                    float sa = 0.f, sb2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; e++) { sa += x[e][0] * x[e][0] + x[e][1] * x[e][1]; sb2 += y[e][0] * y[e][0] + y[e][1] * y[e][1]; }
+                    a = row16_sum(sa);
+                    b = row16_sum(sb2);
+                }
+                const float ab = a * b;
+                const float off = ab > 0.f ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
+                off_max = fmaxf(off_max, off);
+                float cs = 1.f, sn = 0.f, tc = 0.f;
+                if (off > tol) {
+                    float t;
+                    rotation(a, b, c, t, cs, sn);
+                    tc = t * c;
+                }
+                float *wt = nxt + dtop_off, *wb = nxt + dbot_off;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    *reinterpret_cast<f32x2 *>(wt + 32 * e) = cs * x[e] - sn * y[e];
+                    *reinterpret_cast<f32x2 *>(wb + 32 * e) = sn * x[e] + cs * y[e];
+                }
+                if (sub == 0) { wt[32 * E] = a - tc; wb[32 * E] = b + tc; }
+            }
+            __syncthreads();
+        }
+        off_max = wmax(off_max);
+        if (lane == 0) red[wave] = off_max;
+        __syncthreads();
+        float m = 0.f;
+        for (int w = 0; w < nw; w++) m = fmaxf(m, red[w]);
+        __syncthreads();
+        if (m <= stop_cos) { sweep++; break; }               // see jacobi_body for why no verification sweep follows
+    }
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+
+    // ---- eigenvalues lambda = |g| - sigma, eigenvectors g / |g|, sorted descending; the bye has |g| = 0 ----
+    const float *G = (it & 1) ? buf1 : buf0;
+    float *lam = scratch, *inv = scratch + ne;
+    int *rank = reinterpret_cast<int *>(scratch + 2 * ne);
+    for (int j = wave; j < ne; j += nw) {
+        float d = 0.f;
+        for (int i = lane; i < n; i += 64) { const float v = G[(long)j * LDC + i]; d += v * v; }
+        d = wsum(d);
+        if (lane == 0) { const float nr = sqrtf(d); lam[j] = nr > 0.f ? nr - sigma : -3.0e38f; inv[j] = nr > 0.f ? 1.f / nr : 0.f; }
+    }
+    __syncthreads();
+    for (int j = tid; j < ne; j += nthr) {
+        const float me = lam[j];
+        int rk = 0;
+        for (int k = 0; k < ne; k++) {
+            const float o = lam[k];
+            rk += (o > me || (o == me && k < j)) ? 1 : 0;
+        }
+        rank[j] = rk;
+        if (rk < n) evals[rk] = me;
+    }
+    __syncthreads();
+    for (int e = tid; e < ne * n; e += nthr) {
+        const int j = e / n, i = e % n;
+        if (rank[j] < n) Vout[(long)i * ldv + rank[j]] = G[(long)j * LDC + i] * inv[j];
+    }
+}
+
+template <int E>
+void launch_jacobi_seat(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
+                        float stop_cos, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_seat_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(jacobi_seat_kernel<E>, dim3(1), dim3(j16_threads(n)), jseat_lds_bytes(n), s, T, ldt, n, evals, V, ldv, work,
+                       sweeps_out, stop_cos);
+}
+
 inline int col_stride(int n) { return (n + 3) & ~3; }
 
 }  // namespace
@@ -246,7 +562,31 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
     const int ldc = col_stride(n);
     // largest column cosine of a sweep below which the sweep is the last one (see the kernel)
     static const float stop_cos = std::getenv("DLCO_JACOBI_STOP") ? (float)std::atof(std::getenv("DLCO_JACOBI_STOP")) : 1e-3f;
-    if (n <= JACOBI_LDS_MAX_N) {
+    static const bool use_v1 = std::getenv("DLCO_JACOBI_V1") != nullptr;
+    static const bool use_v2 = std::getenv("DLCO_JACOBI_V2") != nullptr;
+    if (n <= J16_MAX_N && !use_v1 && !use_v2) {
+        const int e = j16_chunks(n);
+        if (e == 1) launch_jacobi_seat<1>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
+        else if (e == 2) launch_jacobi_seat<2>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
+        else if (e == 3) launch_jacobi_seat<3>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
+        else launch_jacobi_seat<4>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
+    } else if (n <= J16_MAX_N && !use_v1) {
+        static bool attr16 = false;
+        if (!attr16) {
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            attr16 = true;
+        }
+        const int e = j16_chunks(n), ldc16 = j16_ldc(n);
+        const dim3 grid(1), block(j16_threads(n));
+        const size_t lds16 = j16_lds_bytes(n);
+        if (e == 1) hipLaunchKernelGGL(jacobi16_kernel<1>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
+        else if (e == 2) hipLaunchKernelGGL(jacobi16_kernel<2>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
+        else if (e == 3) hipLaunchKernelGGL(jacobi16_kernel<3>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
+        else hipLaunchKernelGGL(jacobi16_kernel<4>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
+    } else if (n <= JACOBI_LDS_MAX_N) {
         const size_t lds = ((size_t)n * ldc + JW + 4 + n + 4) * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {

@@ -161,7 +161,7 @@ def test_grad_rda_fused_kernel(dlco, ref, F, B, zero_frac):
     ctx.close()
 
 
-@pytest.mark.parametrize("F,rows", [(256, 7), (512, 96), (1024, 128), (384, 40)])
+@pytest.mark.parametrize("F,rows", [(256, 7), (512, 96), (1024, 128), (384, 40), (4096, 96), (2560, 33)])
 def test_tracker_product_kernels(dlco, F, rows):
     """The product kernels of the eigen tracker against fp64: fp32 MFMA, two-way split-bf16 MFMA
     (Chebyshev filter only; stated error budget 3e-5 of |X||G|) and three-way split-bf16 MFMA

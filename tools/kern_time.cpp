@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <functional>
 #include <random>
+#include <string>
 #include <vector>
 
 using namespace dlco;
@@ -27,13 +28,14 @@ static float time_ms(hipStream_t s, int reps, const std::function<void()> &fn)
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool small_only = argc > 1 && std::string(argv[1]) == "small";
     hipStream_t s;
     hipStreamCreate(&s);
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (int n : {32, 64, 96, 128}) {
+    for (int n : {32, 64, 70, 96, 97, 128}) {
         // ---- Cholesky inverse on M = B B^T (rows of B random, nearly orthogonal after scaling) ----
         const int K = 512, ld = 1024;
         std::vector<double> B((size_t)n * K);
@@ -97,6 +99,7 @@ int main()
         std::printf("jacobi_eigh     n=%3d  %.1f us  sweeps %d (%.1f us/sweep)  |TV - VE|max = %.2e  |V^T V - I|max = %.2e\n", n,
                     msj * 1e3, sweeps, msj * 1e3 / std::max(1, sweeps), res, orth);
     }
+    if (small_only) return 0;
     // ---- slab-mode kernels at the 8-GPU shape (F = 8192, slab of 1024 columns, global batch 1600+1600) ----
     {
         const int F = 8192, R = 4096, world = 8, cw = F / world;
