@@ -142,7 +142,7 @@ size_t bf16x2_slab_floats(int M, int N, int ksplit = 0);
 // (N < K) takes ksplit = 4 * K / N so that the launch still fills the chip.
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
-                           float *slab, hipStream_t s, int ksplit = 0, void *plane_lo2 = nullptr);
+                           float *slab, hipStream_t s, int ksplit = 0, void *plane_lo2 = nullptr, bool g_tiled = false);
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).

@@ -75,6 +75,8 @@ struct Bf2Dev {
     const float *G;
     long ldg;
     float *slab;                  // [KS][M][N] raw partial sums
+    int tiled;                    // G is stored as contiguous 128 x 128 tiles, tile (I, J) at ((I * K/128) + J) * 16384 floats
+    int xcd_map;                  // rows kernel: give the workgroups of an XCD one K slice (see the kernel)
 };
 
 template <int MT, int NS>
@@ -188,86 +190,127 @@ __global__ __launch_bounds__(T8) void skinny_bf16x2_kernel(Bf2Dev g)
 // ---- symmetric G, whole matrix: stream ROWS of G ---------------------------------------------------
 // out[:, j] = sum_k X[:, k] G[k][j] = sum_k X[:, k] G[j][k] when G is symmetric: the B operand of output
 // column j is ROW j of G, which is contiguous in memory.  A workgroup owns 128 output columns = 128 rows
-// of G and one K slice, and pulls that 128 x kslice panel through LDS in chunks of 128 x 128 floats
-// (64 KiB), so every global load instruction covers two whole 512-byte row segments (the kernel above
-// fetches 128-byte segments of 16 different rows with dword loads).
-//   * Roles are split by wave, because a wave has ONE in-order counter for its global loads: the four
-//     LOADER waves keep two chunks (128 KiB per CU) of G in flight in registers and copy the chunk
-//     that has arrived into LDS; the eight COMPUTE waves (4 column tiles x 2 K halves of the chunk)
-//     only ever wait for their own X fragments.  One barrier per chunk, two LDS images.
-//   * LDS row stride 132 floats: the 32-byte fragment reads of 32 different rows are conflict-free.
-//   * G is read once: non-temporal loads, so the stream does not evict the X planes from L2.
-//   * Workgroups start at different chunks of their K slice and wrap around: in step, they would all
-//     request the same offset inside a 32-KiB row and pile onto a few HBM channels.
-// Same MFMA schedule per K step and the same slab reduction as above; the K order differs (rotated
-// chunks, halves of a chunk instead of halves of the slice), so the two kernels agree to fp32
-// rounding, not bit for bit.  Deterministic from run to run.
-constexpr int RK_KC = 128;                 // chunk depth (floats)
-constexpr int RK_RS = RK_KC + 4;           // LDS row stride (floats)
+// of G and one K slice and walks it in chunks of 64 k.
+//
+// What the kernel above waits for is not G but its X fragments: every wave fetches them itself, two steps
+// ahead, from an L2 that the G stream keeps flushing (measured: the same pass with deeper or wider G
+// prefetch got slower, 75 -> 87 -> 131 us, whatever the shape of the G accesses; non-temporal G loads
+// keep the planes in L2 but are themselves 30 % slower).  So here BOTH operands of a chunk go through
+// LDS, and the roles are split by wave (a wave has one in-order counter for its loads):
+//   * four LOADER waves keep two chunks in flight in their registers - the 128 x 64 panel of G
+//     (32 KiB) and the chunk's slice of the X planes (contiguous: the planes are stored in fragment
+//     order) - and copy the chunk that has arrived into one of two LDS images;
+//   * eight COMPUTE waves (4 column tiles x 2 halves of the chunk's K steps; two per SIMD, so that one
+//     converts / reads LDS while the other's MFMAs run) multiply the image before it: B fragments are
+//     32-byte reads of 32 different rows (row stride 68 floats: conflict-free), A fragments whole
+//     1-KiB reads; they issue no global load at all.
+// One barrier per chunk.  Same MFMA schedule per K step and the same slab reduction as above; a column's
+// K order is plain ascending inside the slice.  Deterministic.  `tiled`: G stored as contiguous
+// 128 x 128 tiles (a chunk is then half a tile).
+constexpr int RK_KC = 64;                  // chunk depth (floats)
+constexpr int RK_RS = RK_KC + 4;           // LDS row stride of the G image (floats)
 constexpr int RK_T = 768;                  // 8 compute + 4 loader waves
-constexpr size_t RK_LDS_BYTES = (size_t)2 * 128 * RK_RS * sizeof(float);
+constexpr int RK_GBYTES = 128 * RK_RS * 4; // one G image
+__host__ __device__ constexpr int rk_abytes(int mt, int ns) { return ns * mt * 4 * 64 * 16; }     // one A image: ns planes x 4 steps x mt tiles x 1 KiB
+inline size_t rk_lds_bytes(int mt, int ns) { return (size_t)2 * (RK_GBYTES + rk_abytes(mt, ns)); }
 
 template <int MT, int NS>
 __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *buf0 = lds, *buf1 = lds + 128 * RK_RS;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    constexpr int ABYTES = rk_abytes(MT, NS);
+    constexpr int APLANE = MT * 256;                          // 16-byte entries of one plane's chunk slice
+    constexpr int AENT = NS * APLANE;                          // 16-byte entries of one A image
+    constexpr int NA = (AENT + 255) / 256;                     // A entries per loader thread and chunk
+    float *gb0 = reinterpret_cast<float *>(lds_raw), *gb1 = reinterpret_cast<float *>(lds_raw + RK_GBYTES);
+    bf16x8 *ab0 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES), *ab1 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES + ABYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool loader = wave >= 8;
-    const int j0 = blockIdx.x * 128;
-    const int kslice = g.K / (int)gridDim.y;                  // host: a multiple of RK_KC
-    const int kbeg = blockIdx.y * kslice;
+    // Workgroup -> (column tile bx, K slice by).  Workgroups are dealt round-robin to the 8 XCDs, each with
+    // its own L2: all workgroups of one XCD are given the SAME K slice (or as few as possible), so that the
+    // slice of the X planes they all re-read (planes / ks: ~1 MB) stays in that L2 beside the G stream; with
+    // the plain mapping every XCD touches all of the planes (3 - 4.5 MB > its 4 MB L2) and the re-reads,
+    // as many bytes as G itself, come from the Infinity Cache.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, ks = gridDim.y;
+        if (g.xcd_map && ks <= 8 && 8 % ks == 0 && (gx * ks) % 8 == 0 && gx % (8 / ks) == 0) {
+            const int b = by * gx + bx, xcd = b & 7, w = b >> 3, per = 8 / ks;
+            by = xcd / per;
+            bx = w * per + xcd % per;
+        }
+    }
+    const int j0 = bx * 128;
+    const int kslice = g.K / (int)gridDim.y;                  // host: a multiple of 128
+    const int kbeg = by * kslice;
     const int nchunks = kslice / RK_KC;
-    const int rot = (int)(blockIdx.x % (unsigned)nchunks);
-    auto pc = [&](int c) { const int v = c + rot; return v >= nchunks ? v - nchunks : v; };   // position -> chunk of the slice
+    const int st0 = kbeg / 16;                                // K step (of 16) of chunk c, step q: st0 + 4c + q
 
-    if (loader) {
-        // thread -> 16-byte column lc4 of rows lrow + 8u (u < 16) of the chunk
-        const int lt = tid - 512, lrow = lt >> 5, lc4 = lt & 31;
-        const float *gsrc = g.G + (long)(j0 + lrow) * g.ldg + kbeg + 4 * lc4;
-        f32x4 sa[16], sb[16];
-        auto gload = [&](int c, f32x4 (&st)[16]) {
-            const float *p = gsrc + (long)pc(c) * RK_KC;
+    if (wave >= 8) {
+        // ---- loader -----------------------------------------------------------------------------------------
+        // G: thread -> 16-byte column c4 of rows row + 16u (u < 8) of the chunk; buffer loads with one per-lane
+        // byte offset, the row / chunk displacement is a scalar operand.
+        const int lt = tid - 512, grow = lt >> 4, gc4 = lt & 15;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.G), 0, (int)((long)g.K * g.ldg * (long)sizeof(float)), 0x00020000);
+        const long pitch = g.tiled ? 128 : g.ldg;
+        const long base = g.tiled ? ((long)bx * (g.K / 128) + kbeg / 128) * 16384 + (long)grow * 128 + 4 * gc4
+                                  : (long)(j0 + grow) * g.ldg + kbeg + 4 * gc4;
+        const int voff = (int)(base * (long)sizeof(float));
+        const int row16 = (int)(16 * pitch * (long)sizeof(float));
+        const int plane_bytes = MT * 32 * g.K * 2;
+        const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(g.xhi), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(g.xlo), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_lo2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(NS == 3 ? g.xlo2 : g.xlo), 0, plane_bytes, 0x00020000);
+        struct Stage { f32x4 gq[8]; bf16x8 aq[NA]; };
+        Stage s0, s1;
+        auto gload = [&](int c, Stage &st) {
+            const int soff = g.tiled ? ((c >> 1) * 16384 + (c & 1) * 64) * (int)sizeof(float) : c * RK_KC * (int)sizeof(float);
 #pragma unroll
-            for (int u = 0; u < 16; u++) st[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + (long)(8 * u) * g.ldg));
-        };
-        auto gstore = [&](float *buf, const f32x4 (&st)[16]) {
+            for (int u = 0; u < 8; u++) st.gq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + u * row16, 0));
+            // the chunk's slice of every plane is MT * 256 consecutive 16-byte entries (fragment order): entry
+            // lt + 256 v belongs to plane v / MT -> static plane per v, scalar offset, one per-lane offset (16 lt)
+            const int a0 = (st0 + 4 * c) * MT * 64 * 16;       // byte offset of the slice inside a plane
 #pragma unroll
-            for (int u = 0; u < 16; u++) *reinterpret_cast<f32x4 *>(buf + (lrow + 8 * u) * RK_RS + 4 * lc4) = st[u];
+            for (int v = 0; v < NA; v++) {
+                const __amdgpu_buffer_rsrc_t &ra = (v / MT == 0) ? rs_hi : ((v / MT == 1) ? rs_lo : rs_lo2);
+                st.aq[v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, 16 * lt, a0 + (v % MT) * 256 * 16, 0));
+            }
         };
-        // position c is multiplied during iteration c; it is stored at the start of iteration c - 1
-        // (position 0: before the loop) and was requested two iterations before that
-        gload(0, sa);
-        gload(nchunks > 1 ? 1 : 0, sb);
-        gstore(buf0, sa);
-        gload(nchunks > 2 ? 2 : 0, sa);
+        auto gstore = [&](int buf, const Stage &st) {
+            float *gb = buf ? gb1 : gb0;
+            bf16x8 *ab = buf ? ab1 : ab0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) *reinterpret_cast<f32x4 *>(gb + (grow + 16 * u) * RK_RS + 4 * gc4) = st.gq[u];
+#pragma unroll
+            for (int v = 0; v < NA; v++) ab[lt + 256 * v] = st.aq[v];
+        };
+        // Chunk p is multiplied during iteration p, copied to LDS image p & 1 at the start of iteration
+        // p - 1 and requested at iteration p - 3 into register set p & 1 (chunks 0..2: before the loop).
+        const int last = nchunks - 1;
+        gload(0, s0);
+        gload(min(1, last), s1);
+        gstore(0, s0);
+        gload(min(2, last), s0);
         __syncthreads();
+        // iteration cc: copy chunk cc+1 (waiting in `set`) into image `buf`, request chunk cc+3 into the same registers
+        auto full = [&](int buf, Stage &set, int cc) { gstore(buf, set); gload(cc + 3, set); __syncthreads(); };
+        auto part = [&](int buf, Stage &set, int cc) {
+            if (cc >= nchunks) return;
+            if (cc + 1 < nchunks) gstore(buf, set);
+            if (cc + 3 < nchunks) gload(cc + 3, set);
+            __syncthreads();
+        };
         int c = 0;
-        // steady state, free of branches around the loads (after a conditional load the compiler can no
-        // longer count which requests are older than the ones it waits for, and drains them all)
-        for (; c + 4 < nchunks; c += 2) {
-            gstore(buf1, sb);                                  // iteration c: position c+1 -> buf1, request c+3
-            gload(c + 3, sb);
-            __syncthreads();
-            gstore(buf0, sa);                                  // iteration c+1: position c+2 -> buf0, request c+4
-            gload(c + 4, sa);
-            __syncthreads();
-        }
-        for (; c < nchunks; c += 2) {
-            // iteration c (even): store position c+1 (in sb) into buf1, request position c+3 into sb
-            if (c + 1 < nchunks) gstore(buf1, sb);
-            if (c + 3 < nchunks) gload(c + 3, sb);
-            __syncthreads();
-            if (c + 1 >= nchunks) break;
-            // iteration c+1 (odd): store position c+2 (in sa) into buf0, request position c+4 into sa
-            if (c + 2 < nchunks) gstore(buf0, sa);
-            if (c + 4 < nchunks) gload(c + 4, sa);
-            __syncthreads();
-        }
+        // steady state: no branch around a load (after one the compiler can no longer tell which requests
+        // are older than the ones it waits for, and drains them all)
+        for (; c + 4 < nchunks; c += 2) { full(1, s1, c); full(0, s0, c + 1); }
+        // tail (at most four iterations): the same sequence with guards
+        part(1, s1, c); part(0, s0, c + 1); part(1, s1, c + 2); part(0, s0, c + 3);
         __syncthreads();                                       // the compute waves' K-half exchange
         return;
     }
 
+    // ---- compute: wave = (32-column tile, half of the chunk's four K steps), operands from LDS only ----------
     const int lc = lane & 31, lh = lane >> 5;
     const int nt = wave & 3, kh = wave >> 2;
     f32x16 acc[MT];
@@ -276,22 +319,23 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
 
-    auto load_a = [&](int s, bf16x8 (&h)[MT], bf16x8 (&l)[MT], bf16x8 (&m2)[NS == 3 ? MT : 1]) {
+    // operands of one K step, read from the LDS images: issued one step ahead of the MFMAs that use them
+    // (this wave is alone on its SIMD as far as LDS latency goes)
+    struct Frag { f32x4 g0, g1; bf16x8 a[NS][MT]; };
+    auto fetch = [&](const float *gb, const bf16x8 *ab, int q, Frag &f) {
+        const float *p = gb + (nt * 32 + lc) * RK_RS + 16 * q + 8 * lh;
+        f.g0 = *reinterpret_cast<const f32x4 *>(p);
+        f.g1 = *reinterpret_cast<const f32x4 *>(p + 4);
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const long idx = ((long)s * MT + t) * 64 + lane;
-            h[t] = g.xhi[idx];
-            l[t] = g.xlo[idx];
-            if (NS == 3) m2[t] = g.xlo2[idx];
-        }
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) f.a[n][t] = ab[n * APLANE + (q * MT + t) * 64 + lane];
     };
-    auto compute = [&](const float *buf, int q, const bf16x8 (&h)[MT], const bf16x8 (&l)[MT], const bf16x8 (&m2)[NS == 3 ? MT : 1]) {
-        const float *p = buf + (nt * 32 + lc) * RK_RS + 16 * (4 * kh + q) + 8 * lh;
-        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p), g1 = *reinterpret_cast<const f32x4 *>(p + 4);
+    auto multiply = [&](const Frag &f) {
         bf16x8 bh, bl, bl2;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float v = j < 4 ? g0[j & 3] : g1[j & 3];
+            const float v = j < 4 ? f.g0[j & 3] : f.g1[j & 3];
             bh[j] = (__bf16)v;
             const float r1 = v - (float)bh[j];
             bl[j] = (__bf16)r1;
@@ -300,40 +344,29 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
 #pragma unroll
         for (int t = 0; t < MT; t++) {
             if (NS == 3) {                                   // smallest terms first
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[t], bl2, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m2[t], bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l[t], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bl2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[NS - 1][t], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][t], bl, acc[t], 0, 0, 0);
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[t], bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l[t], bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[t], bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][t], bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bh, acc[t], 0, 0, 0);
         }
     };
-
-    bf16x8 ah[MT], al[MT], ahn[MT], aln[MT];
-    bf16x8 am[NS == 3 ? MT : 1], amn[NS == 3 ? MT : 1];
-    // K step (of 16) of this wave inside the chunk at position c: kbeg/16 + 8*pc(c) + 4kh + q, q = 0..3
-    const int st0 = kbeg / 16 + 4 * kh;
-    load_a(st0 + 8 * pc(0), ah, al, am);
-    load_a(st0 + 8 * pc(0) + 1, ahn, aln, amn);
+    Frag fa;                                                  // (the SIMD's other compute wave covers the LDS latency)
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
-        const float *cur = (c & 1) ? buf1 : buf0;
-        const int st = st0 + 8 * pc(c);
-        const int stn = st0 + 8 * pc(c + 1 < nchunks ? c + 1 : c);   // first two steps of the next chunk (last: reloaded, unused)
-        compute(cur, 0, ah, al, am);
-        load_a(st + 2, ah, al, am);
-        compute(cur, 1, ahn, aln, amn);
-        load_a(st + 3, ahn, aln, amn);
-        compute(cur, 2, ah, al, am);
-        load_a(stn, ah, al, am);
-        compute(cur, 3, ahn, aln, amn);
-        load_a(stn + 1, ahn, aln, amn);
+        const float *gb = (c & 1) ? gb1 : gb0;
+        const bf16x8 *ab = (c & 1) ? ab1 : ab0;
+        fetch(gb, ab, 2 * kh, fa);
+        multiply(fa);
+        fetch(gb, ab, 2 * kh + 1, fa);
+        multiply(fa);
         __syncthreads();
     }
 
     // ---- the two K halves of a column tile meet in LDS; the raw slice sum goes to its slab ------------
-    float *red = lds;                                         // 4*MT*16*64 floats <= one chunk buffer
+    float *red = reinterpret_cast<float *>(lds_raw);          // 4*MT*16*64 floats <= the two G images
     if (kh == 1) {
 #pragma unroll
         for (int a = 0; a < MT; a++)
@@ -342,15 +375,15 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
     }
     __syncthreads();
     if (kh == 0) {
-        float *slab = g.slab + (long)blockIdx.y * g.M * g.N;
+        float *slab = g.slab + (long)by * g.M * g.N;
         const int col = j0 + nt * 32 + lc;
 #pragma unroll
         for (int a = 0; a < MT; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float s = acc[a][r] + red[((nt * MT + a) * 16 + r) * 64 + lane];
+                const float sum = acc[a][r] + red[((nt * MT + a) * 16 + r) * 64 + lane];
                 const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (i < g.M) slab[(long)i * g.N + col] = s;
+                if (i < g.M) slab[(long)i * g.N + col] = sum;
             }
     }
 }
@@ -358,13 +391,14 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
 template <int MT, int NS>
 void launch_rows(const Bf2Dev &g, dim3 grid, hipStream_t s)
 {
+    const size_t lds = rk_lds_bytes(MT, NS);
     static bool attr = false;
     if (!attr) {
         DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_rows_kernel<MT, NS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)RK_LDS_BYTES));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((skinny_rows_kernel<MT, NS>), grid, dim3(RK_T), RK_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((skinny_rows_kernel<MT, NS>), grid, dim3(RK_T), lds, s, g);
 }
 
 }  // namespace
@@ -375,7 +409,7 @@ size_t bf16x2_slab_floats(int M, int N, int ksplit) { return (size_t)(ksplit > 0
 // Returns false when the shape is not supported (caller falls back to the fp32 kernel).
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
-                           float *slab, hipStream_t s, int ksplit, void *plane_lo2)
+                           float *slab, hipStream_t s, int ksplit, void *plane_lo2, bool g_tiled)
 {
     const int mt = (M + 31) / 32;
     const int ks = ksplit > 0 ? ksplit : KS;
@@ -388,11 +422,15 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
     g.M = M; g.N = N; g.K = K;
     g.xhi = static_cast<const bf16x8 *>(plane_hi); g.xlo = static_cast<const bf16x8 *>(plane_lo);
     g.xlo2 = static_cast<const bf16x8 *>(plane_lo2);
-    g.G = G; g.ldg = ldg; g.slab = slab;
+    g.G = G; g.ldg = ldg; g.slab = slab; g.tiled = g_tiled ? 1 : 0;
+    static const int xcd_map = std::getenv("DLCO_NO_XCDMAP") == nullptr ? 1 : 0;
+    g.xcd_map = xcd_map;
     const dim3 grid(N / 128, ks), block(T8);
     // whole symmetric matrix: stream its rows through LDS (skinny_rows_kernel)
     static const bool rows_ok = std::getenv("DLCO_PRODUCT_V1") == nullptr;
-    if (rows_ok && N == K && K % (RK_KC * ks) == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0) {
+    // (four row tiles with the three-way split do not fit the register budget of the split-role kernel)
+    if (rows_ok && N == K && K % (128 * ks) == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0 &&
+        (long)K * ldg * 4 < (1L << 31) && !(mt == 4 && plane_lo2)) {
         if (plane_lo2) {
             if (mt == 1) launch_rows<1, 3>(g, grid, s);
             else if (mt == 2) launch_rows<2, 3>(g, grid, s);
@@ -408,6 +446,7 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
         splitk_reduce_f32(slab, ks, M, N, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
         return true;
     }
+    if (g_tiled) return false;                                 // only the row-streaming kernel reads the tiled layout
     if (plane_lo2) {                                         // three-way split: fp32-level accuracy
         if (mt == 1) hipLaunchKernelGGL((skinny_bf16x2_kernel<1, 3>), grid, block, 0, s, g);
         else if (mt == 2) hipLaunchKernelGGL((skinny_bf16x2_kernel<2, 3>), grid, block, 0, s, g);

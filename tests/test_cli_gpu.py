@@ -98,3 +98,49 @@ def test_hdf5_round_trip_when_libhdf5_is_present(tools, dataset, tmp_path):
     assert os.path.getsize(dst) > 64 * 64 * 4
     q = subprocess.run([ev, dst, src], capture_output=True, text=True, timeout=300)
     assert q.returncode == 0 and STAT.match(q.stdout.strip()), q.stderr
+
+
+def _last_entry(stdout):
+    best = [l for l in stdout.splitlines() if l.startswith(("Best: ", "Step: "))]
+    f = re.split(r"[ :()]+", best[-1])
+    # Best 100 Loss x Regul y Obj z (zb) Rank r (rb) ...
+    return dict(t=int(f[1]), loss=float(f[3]), regul=float(f[5]), rank=int(f[10]))
+
+
+def test_pj_learn_two_processes_on_one_gpu_match_the_single_process_run(tools, dataset, tmp_path):
+    """`pj-learn -gpus 2`: the parent forks two ranks before any GPU call; each runs the column-sharded
+    step on its own context and the all-gathers go through the library.  A box of this pool has one
+    GPU and RCCL refuses two ranks on one device, so the ranks share device 0 and use the library's
+    shared-memory transport (-comm host); with -comm rccl the same processes call ncclAllGather.
+    Same global batch as the single-process run => the same computation up to fp32 summation grouping."""
+    pj, _ = tools
+    src, D, L = dataset
+    args = ["-mu", "0.004", "-gamma", "0.5", "-iters", "100", "-batch", "40"]
+    one = subprocess.run([pj, src, str(tmp_path / "one")] + args, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr
+    two = subprocess.run([pj, src, str(tmp_path / "two"), "-gpus", "2", "-devices", "0,0", "-comm", "host"] + args,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr
+    # one log, printed by rank 0 only, same grammar and header
+    assert two.stdout.splitlines()[:13] == one.stdout.splitlines()[:13]
+    a, b = _last_entry(one.stdout), _last_entry(two.stdout)
+    assert a["t"] == b["t"] == 100 and abs(a["rank"] - b["rank"]) <= 1
+    assert abs(a["loss"] - b["loss"]) <= 0.02 * a["loss"] + 1e-5 and abs(a["regul"] - b["regul"]) <= 0.02 * a["regul"] + 1e-5
+    W1, W2 = np.load(tmp_path / "one" / "W.npy"), np.load(tmp_path / "two" / "W.npy")
+    A1, A2 = np.load(tmp_path / "one" / "A.npy"), np.load(tmp_path / "two" / "A.npy")
+    assert abs(W1.shape[0] - W2.shape[0]) <= 1 and A1.shape == A2.shape
+    assert relmax(A2, A1) <= 2e-2                      # 100 free-running steps on either side
+    assert relmax(W2.T.astype(np.float64) @ W2.astype(np.float64), A2) <= 1e-5
+
+
+def test_pj_learn_multi_process_failure_exits_nonzero(tools, dataset, tmp_path):
+    """A rank that cannot start (device 99 does not exist) exits non-zero; the parent stops the other
+    rank instead of leaving it in a collective, and reports failure."""
+    pj, _ = tools
+    src, _, _ = dataset
+    p = subprocess.run([pj, src, str(tmp_path / "bad"), "-gpus", "2", "-devices", "0,99", "-comm", "host", "-iters", "100", "-batch", "40"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3
+    assert "rank 1" in p.stderr
+    q = subprocess.run([pj, src, str(tmp_path / "bad"), "-gpus", "2", "-batch", "41"], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 1 and "Usage:" in q.stdout

@@ -31,6 +31,32 @@ static float time_ms(hipStream_t s, int reps, const std::function<void()> &fn)
 int main(int argc, char **argv)
 {
     const bool small_only = argc > 1 && std::string(argv[1]) == "small";
+    const bool prod_only = argc > 1 && std::string(argv[1]) == "prod";
+    hipStream_t s0;
+    hipStreamCreate(&s0);
+    if (prod_only) {
+        // one pass of the tracker over a symmetric F x F matrix: two-way (filter) and three-way (Rayleigh-Ritz) split
+        const int F = 8192, M = 96;
+        std::mt19937 r0(11);
+        std::normal_distribution<float> g0(0.f, 1.f);
+        DevBuf<float> C, X, out, slab; DevBuf<char> ph, pl, pl2;
+        C.alloc((size_t)F * F); X.alloc((size_t)128 * F); out.alloc((size_t)128 * F); slab.alloc(bf16x2_slab_floats(128, F, 8));   // the ks = 8 case below needs 8 slices
+        ph.alloc(bf16x2_plane_bytes(128, F)); pl.alloc(bf16x2_plane_bytes(128, F)); pl2.alloc(bf16x2_plane_bytes(128, F));
+        std::vector<float> h((size_t)128 * F);
+        for (auto &x : h) x = g0(r0);
+        hipMemcpy(X.p, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        for (int i = 0; i < 64; i++) hipMemcpy(C.p + (size_t)i * 128 * F, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        const float a = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0); });
+        const float b = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 0, pl2.p); });
+        const float c8 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 8); });
+        const float t2 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 0, nullptr, true); });
+        const float t3 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 0, pl2.p, true); });
+        std::printf("product on a TILED matrix (128 x 128 tiles contiguous): two-way %.1f us (%.2f TB/s), three-way %.1f us (%.2f TB/s)\n", t2 * 1e3,
+                    4.0 * F * F / (t2 * 1e-3) / 1e12, t3 * 1e3, 4.0 * F * F / (t3 * 1e-3) / 1e12);
+        std::printf("product M=%d F=%d: two-way %.1f us (%.2f TB/s), three-way %.1f us (%.2f TB/s), two-way ks=8 %.1f us  [split + kernel + reduce]\n", M, F,
+                    a * 1e3, 4.0 * F * F / (a * 1e-3) / 1e12, b * 1e3, 4.0 * F * F / (b * 1e-3) / 1e12, c8 * 1e3);
+        return 0;
+    }
     hipStream_t s;
     hipStreamCreate(&s);
     std::mt19937 rng(7);
