@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1 headline mode: per-GPU batch fixed (weak) or global batch fixed at --batch (strong)")
     ap.add_argument("--no-other-modes", action="store_true", help="N > 1: measure the headline mode only")
+    ap.add_argument("--bf16", action="store_true",
+                    help="BASELINE configs[4] variant: the gradient SYRK on the bf16 matrix cores with fp32 accumulation "
+                         "(cfg.grad_bf16; not the reference's arithmetic, gated on the FPR@95 band)")
     ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
     ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
     args = ap.parse_args()
@@ -309,7 +312,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ddist = importlib.import_module("opencv-dlco_amd.dist")
-    kw = dict(eig_guard=args.guard, eig_tol=args.eig_tol)
+    kw = dict(eig_guard=args.guard, eig_tol=args.eig_tol, grad_bf16=1 if args.bf16 else 0)
 
     def make_runner(dp_mode, scaling, data_from=None):
         """weak: global batch world*Bl; strong: global batch Bl (must divide by world)."""
@@ -369,6 +372,7 @@ def main():
         flops_launch /= world
     t_syrk = ms_syrk / max(n_syrk, 1) * 1e-3
     ach = flops_launch / t_syrk / 1e12 if n_syrk else None
+    peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS        # dense bf16 MFMA peak (same guide) for the --bf16 variant
     exec_flops = flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128))
     traffic, traffic_src = pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else (None, None)
     sq = committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
@@ -392,7 +396,7 @@ def main():
         "higher_is_better": True,
         "scaling": R.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16 (gradient MFMA inputs; f32 accumulate, f32 elsewhere)" if args.bf16 else "f32",
         "data": "synthetic",
         "config": {
             "workload": "pj-learn %s: %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
@@ -414,9 +418,9 @@ def main():
             "bound": "mfma",
             "kernel": "grad_syrk_rda (fused weighted SYRK + dual average)",
             "achieved": ach,
-            "peak": PEAK_F32_MFMA_TFLOPS,
+            "peak": peak_mfma,
             "unit": "TFLOP/s",
-            "frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
+            "frac": (ach / peak_mfma) if ach else None,
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s); algorithmic bytes 8*F*F + 4*K*F = %d"
                             % (traffic_src, int(8 * F * F + 4 * k_mean * F)),
@@ -426,7 +430,7 @@ def main():
             "mean_active_rows_per_launch": k_mean,
             "executed_flops_per_launch": exec_flops,
             # the kernel computes the upper tiles only: executed/peak is what the MFMA pipe really does
-            "executed_frac": (exec_flops / t_syrk / 1e12 / PEAK_F32_MFMA_TFLOPS) if n_syrk else None,
+            "executed_frac": (exec_flops / t_syrk / 1e12 / peak_mfma) if n_syrk else None,
             "mfma_busy_frac_pmc": mfma_busy,
             # kernel path only (P1+P2+V1+Q1+U1), (ii) end to end incl. the PSD projection
             "flops_per_pair_row": flops_pair_row,

@@ -59,7 +59,12 @@ typedef struct dlco_cfg {
     int32_t  strict_conv; /* 1: dlco_step returns DLCO_ERR_NOCONV when the tracker misses eig_tol (the step is
                           * still applied).  0 (default): the miss is counted (dlco_counters out[2],
                           * dlco_log_entry.nonconv) and the run goes on with the approximate W.            */
-    int32_t  reserved[6];
+    int32_t  grad_bf16;  /* 1: the gradient SYRK (Q1) multiplies on the bf16 matrix cores with fp32 accumulation
+                          * (operands rounded to bf16 when the MFMA fragments are read; gather, weights, dual
+                          * average stay fp32) - BASELINE configs[4].  Not the reference's arithmetic: the
+                          * result is gated on the FPR@95 band, not on the fp32 tolerances.  Needs F % 128 == 0.
+                          * 0 (default): exact fp32 MFMA.                                                    */
+    int32_t  reserved[5];
 } dlco_cfg;
 
 void dlco_cfg_default(dlco_cfg *cfg);
@@ -260,6 +265,38 @@ int dlco_counters(const dlco_ctx *ctx, int64_t out[8]);
 /* Tracker statistics since creation: filter/RR iterations, H-products (in rows), restarts. */
 int dlco_eig_stats(const dlco_ctx *ctx, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps,
                    int32_t *block_rows);
+
+/* ======================================================================================================
+ * pr-learn — the pooling-region stage that precedes pj-learn.
+ * Replaces the loop and the LogStep block of src/pr-learn.cpp:229-434 and ComputePRStats
+ * (src/misc.cpp:171-264).  L1-regularised dual averaging on the weight vector w [F] of the F candidate
+ * pooling regions: one (positive, negative) row pair per iteration, strictly sequential, so a window of
+ * iterations is ONE kernel launch on one workgroup (w and dfAvg in registers).  The arithmetic follows
+ * the reference operation for operation (single-thread order of its OpenMP loop), see
+ * opencv-dlco_amd/csrc/kernels_pr.hip.
+ * ====================================================================================================== */
+typedef struct dlco_pr_ctx dlco_pr_ctx;
+const char *dlco_pr_last_error(const dlco_pr_ctx *ctx);
+/* F = FeatDim (5120 in the reference's runs; a multiple of 4, at most 8192), N rows; defaults of the
+ * reference: mu 0.025, gamma 0.10, seed 2215 (src/pr-learn.cpp:78-82,241). */
+int dlco_pr_create(dlco_pr_ctx **out, int32_t F, int32_t N, float mu, float gamma, uint64_t seed, int32_t device);
+void dlco_pr_destroy(dlco_pr_ctx *ctx);
+int dlco_pr_device_name(const dlco_pr_ctx *ctx, char *buf, size_t cap, int *cc_major, int *cc_minor);
+/* Distance [N,F] f32 + Label [N] u8; index build, randShuffle and 80/20 split, src/pr-learn.cpp:229-253. */
+int dlco_pr_set_data(dlco_pr_ctx *ctx, const float *dists_host, const uint8_t *labels_host);
+int dlco_pr_get_index(const dlco_pr_ctx *ctx, int32_t *n_pos, int32_t *n_pos_trn, int32_t *n_neg, int32_t *n_neg_trn);
+/* n iterations of src/pr-learn.cpp:302-329 (sample, subtract, dot product, dual average, soft threshold). */
+int dlco_pr_steps(dlco_pr_ctx *ctx, uint32_t n);
+int dlco_pr_get_state(dlco_pr_ctx *ctx, uint32_t *t, float *w_host /* F */, float *dfavg_host /* F */);
+int dlco_pr_set_state(dlco_pr_ctx *ctx, uint32_t t, const float *w_host, const float *dfavg_host);
+/* Validation objective of the current w, src/pr-learn.cpp:340-361: hinge loss over validation positives x
+ * negatives / (nPosVal * nNegVal), regul = mu * sum|w|, nnz = countNonZero(w). */
+int dlco_pr_validate(dlco_pr_ctx *ctx, float *loss_val, float *regul, int32_t *nnz);
+/* ComputePRStats (src/misc.cpp:171-264) for w_host (NULL: the current w) on all N rows.  PRParams is the
+ * [pr_rows >= 8*F, pr_cols] table of the filter file; nPR / Dim / nzDim as the reference counts them; when
+ * max_dim != -1 and Dim > max_dim the function returns before the ROC pass (fpr95 / auc untouched). */
+int dlco_pr_stats(dlco_pr_ctx *ctx, const float *w_host, const float *prparams_host, int32_t pr_rows, int32_t pr_cols,
+                  int32_t nchannels, int32_t max_dim, int32_t *nPR, int32_t *dim, int32_t *nzdim, float *fpr95, double *auc);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,8 @@ class Cfg(C.Structure):
         ("seed", C.c_uint64),
         ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
         ("eig_tol", C.c_float), ("eig_guard", C.c_int32), ("eig_max_iter", C.c_int32),
-        ("shard", C.c_int32), ("strict_conv", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("shard", C.c_int32), ("strict_conv", C.c_int32), ("grad_bf16", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -119,6 +119,19 @@ def load():
     L.dlco_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.dlco_eig_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
     L.dlco_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.dlco_pr_last_error.restype = C.c_char_p
+    L.dlco_pr_last_error.argtypes = [vp]
+    L.dlco_pr_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32]
+    L.dlco_pr_destroy.argtypes = [vp]
+    L.dlco_pr_destroy.restype = None
+    L.dlco_pr_device_name.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dlco_pr_set_data.argtypes = [vp, f32p, u8p]
+    L.dlco_pr_get_index.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.dlco_pr_steps.argtypes = [vp, C.c_uint32]
+    L.dlco_pr_get_state.argtypes = [vp, C.POINTER(C.c_uint32), f32p, f32p]
+    L.dlco_pr_set_state.argtypes = [vp, C.c_uint32, f32p, f32p]
+    L.dlco_pr_validate.argtypes = [vp, f32p, f32p, i32p]
+    L.dlco_pr_stats.argtypes = [vp, f32p, f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, i32p, f32p, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -156,13 +169,14 @@ class Context:
     """One pj-learn trainer on one GPU (thin wrapper over dlco_ctx)."""
 
     def __init__(self, F, N, B=200, mu=0.001, gamma=0.5, seed=2215, device=0, rank=0, world=1,
-                 eig_tol=None, eig_guard=None, eig_max_iter=None, shard=0, strict_conv=0):
+                 eig_tol=None, eig_guard=None, eig_max_iter=None, shard=0, strict_conv=0, grad_bf16=0):
         self.L = load()
         cfg = Cfg()
         self.L.dlco_cfg_default(C.byref(cfg))
         cfg.F, cfg.N, cfg.B, cfg.mu, cfg.gamma, cfg.seed = F, N, B, mu, gamma, seed
         cfg.device, cfg.rank, cfg.world, cfg.shard = device, rank, world, shard
         cfg.strict_conv = strict_conv
+        cfg.grad_bf16 = grad_bf16
         if eig_tol is not None:
             cfg.eig_tol = eig_tol
         if eig_guard is not None:
@@ -405,3 +419,68 @@ class Context:
         a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         self._ck(self.L.dlco_eig_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
         return dict(iters=a.value, product_rows=b.value, jacobi_sweeps=c_.value, block_rows=d.value)
+
+
+class PrContext:
+    """pr-learn: L1-regularised dual averaging on the pooling-region weights (thin wrapper over dlco_pr_ctx)."""
+
+    def __init__(self, F, N, mu=0.025, gamma=0.10, seed=2215, device=0):
+        self.L = load()
+        self.F, self.N = F, N
+        h = C.c_void_p()
+        rc = self.L.dlco_pr_create(C.byref(h), F, N, mu, gamma, seed, device)
+        if rc != OK:
+            raise DlcoError(rc, self.L.dlco_pr_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dlco_pr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise DlcoError(rc, self.L.dlco_pr_last_error(self.h).decode())
+
+    def set_data(self, dists, labels):
+        d, l = _f32(dists), np.ascontiguousarray(labels, np.uint8).ravel()
+        assert d.shape == (self.N, self.F) and l.size == self.N
+        self._ck(self.L.dlco_pr_set_data(self.h, _p(d, f32p), _p(l, u8p)))
+
+    def index(self):
+        a, b, c_, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self.L.dlco_pr_get_index(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
+        return dict(n_pos=a.value, n_pos_trn=b.value, n_neg=c_.value, n_neg_trn=d.value)
+
+    def steps(self, n):
+        self._ck(self.L.dlco_pr_steps(self.h, n))
+
+    def state(self):
+        t = C.c_uint32()
+        w, df = np.empty(self.F, np.float32), np.empty(self.F, np.float32)
+        self._ck(self.L.dlco_pr_get_state(self.h, C.byref(t), _p(w, f32p), _p(df, f32p)))
+        return dict(t=t.value, w=w, dfavg=df)
+
+    def set_state(self, t, w=None, dfavg=None):
+        w = None if w is None else _f32(w)
+        d = None if dfavg is None else _f32(dfavg)
+        self._ck(self.L.dlco_pr_set_state(self.h, t, _p(w, f32p), _p(d, f32p)))
+
+    def validate(self):
+        lo, rg, nz = C.c_float(), C.c_float(), C.c_int32()
+        self._ck(self.L.dlco_pr_validate(self.h, C.byref(lo), C.byref(rg), C.byref(nz)))
+        return lo.value, rg.value, nz.value
+
+    def stats(self, prparams, w=None, nchannels=8, max_dim=-1):
+        p = _f32(prparams)
+        wv = None if w is None else _f32(w)
+        npr, dim, nz, f, a = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float(-1.0), C.c_double(0.0)
+        self._ck(self.L.dlco_pr_stats(self.h, _p(wv, f32p), _p(p, f32p), p.shape[0], p.shape[1], nchannels, max_dim,
+                                      C.byref(npr), C.byref(dim), C.byref(nz), C.byref(f), C.byref(a)))
+        return dict(nPR=npr.value, dim=dim.value, nzdim=nz.value, fpr95=f.value, auc=a.value)

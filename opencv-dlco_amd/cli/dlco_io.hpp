@@ -208,6 +208,67 @@ struct Writer {
     ~Writer() { if (f >= 0) h5().H5Fclose(f); }
 };
 
+// Appends one f32 row to the 2-D dataset `name` of `path`, creating it with unlimited rows, chunk {1, cols}
+// and gzip 9 when it does not exist yet (the "w" dataset of pr-learn, src/pr-learn.cpp:391-410).  In the
+// .npy-directory form the rows accumulate in `path`/`name`.npy (the file is rewritten).
+inline void append_row_f32(const std::string &path, const char *name, const float *row, size_t cols)
+{
+    if (!is_h5(path)) {
+        mkdir(path.c_str(), 0777);
+        const std::string f = path + "/" + name + ".npy";
+        std::vector<size_t> shape;
+        std::vector<char> bytes;
+        struct stat st;
+        if (::stat(f.c_str(), &st) == 0) npy_read(f, "<f4", 4, shape, bytes);
+        if (shape.size() != 2 || shape[1] != cols) { shape = {0, cols}; bytes.clear(); }
+        bytes.insert(bytes.end(), reinterpret_cast<const char *>(row), reinterpret_cast<const char *>(row) + cols * 4);
+        shape[0]++;
+        npy_write(f, bytes.data(), "<f4", 4, shape);
+        return;
+    }
+    H5 &L = h5();
+    if (!L.load()) throw std::runtime_error("HDF5 output requested but libhdf5 could not be loaded");
+    typedef H5::hid_t hid_t;
+    auto sym = [&](const char *n) { void *p = dlsym(L.h, n); if (!p) throw std::runtime_error(std::string("libhdf5 lacks ") + n); return p; };
+    auto H5Pcreate = reinterpret_cast<hid_t (*)(hid_t)>(sym("H5Pcreate"));
+    auto H5Pset_chunk = reinterpret_cast<int (*)(hid_t, int, const unsigned long long *)>(sym("H5Pset_chunk"));
+    auto H5Pset_deflate = reinterpret_cast<int (*)(hid_t, unsigned)>(sym("H5Pset_deflate"));
+    auto H5Pclose = reinterpret_cast<int (*)(hid_t)>(sym("H5Pclose"));
+    auto H5Dset_extent = reinterpret_cast<int (*)(hid_t, const unsigned long long *)>(sym("H5Dset_extent"));
+    auto H5Sselect_hyperslab = reinterpret_cast<int (*)(hid_t, int, const unsigned long long *, const unsigned long long *,
+                                                          const unsigned long long *, const unsigned long long *)>(sym("H5Sselect_hyperslab"));
+    hid_t *dcpl_cls = reinterpret_cast<hid_t *>(sym("H5P_CLS_DATASET_CREATE_ID_g"));
+    struct stat st;
+    hid_t f = ::stat(path.c_str(), &st) == 0 ? L.H5Fopen(path.c_str(), 1 /* H5F_ACC_RDWR */, 0) : L.H5Fcreate(path.c_str(), 2, 0, 0);
+    if (f < 0) throw std::runtime_error("cannot open " + path + " for writing");
+    hid_t d;
+    unsigned long long rows = 0;
+    if (L.H5Lexists(f, name, 0) > 0) {
+        d = L.H5Dopen2(f, name, 0);
+        const hid_t s0 = L.H5Dget_space(d);
+        unsigned long long dims[2] = {0, 0};
+        L.H5Sget_simple_extent_dims(s0, dims, nullptr);
+        L.H5Sclose(s0);
+        if (dims[1] != cols) { L.H5Dclose(d); L.H5Fclose(f); throw std::runtime_error(path + ": dataset " + name + " has another width"); }
+        rows = dims[0];
+    } else {
+        const unsigned long long dims[2] = {0, cols}, maxd[2] = {~0ULL /* H5S_UNLIMITED */, cols}, chunk[2] = {1, cols};
+        const hid_t sp = L.H5Screate_simple(2, dims, maxd), pl = H5Pcreate(*dcpl_cls);
+        H5Pset_chunk(pl, 2, chunk);
+        H5Pset_deflate(pl, 9);
+        d = L.H5Dcreate2(f, name, L.native_float, sp, 0, pl, 0);
+        H5Pclose(pl); L.H5Sclose(sp);
+        if (d < 0) { L.H5Fclose(f); throw std::runtime_error(path + ": cannot create dataset " + name); }
+    }
+    const unsigned long long newdims[2] = {rows + 1, cols}, start[2] = {rows, 0}, count[2] = {1, cols};
+    int rc = H5Dset_extent(d, newdims);
+    const hid_t fs = L.H5Dget_space(d), ms = L.H5Screate_simple(2, count, nullptr);
+    if (rc >= 0) rc = H5Sselect_hyperslab(fs, 0 /* H5S_SELECT_SET */, start, nullptr, count, nullptr);
+    if (rc >= 0) rc = L.H5Dwrite(d, L.native_float, ms, fs, 0, row);
+    L.H5Sclose(ms); L.H5Sclose(fs); L.H5Dclose(d); L.H5Fclose(f);
+    if (rc < 0) throw std::runtime_error(path + ": append to dataset " + name + " failed");
+}
+
 // GDAL-style progress bar of the reference (src/misc.cpp:45-76)
 inline int term_progress(double complete, int last_tick)
 {

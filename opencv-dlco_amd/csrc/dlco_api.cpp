@@ -234,7 +234,7 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
         (!c->shard || (c->comm.c0 % 128 == 0 && c->comm.cw % 128 == 0))) {
         c->prof.begin(PROF_GRAD_SYRK);
         const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream,
-                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0);
+                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;

@@ -151,7 +151,7 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
 // of C are computed and stored (all rows, no mirror); both must be multiples of 128.
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
-                  int slab_cols = 0);
+                  int slab_cols = 0, bool bf16 = false);
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,

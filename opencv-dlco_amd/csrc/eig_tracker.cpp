@@ -106,8 +106,10 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     // the split-bf16 kernels take up to 128 rows: a taller block goes through them in row chunks
     // (one HBM-bound pass over G per chunk, still cheaper than the generic fp32 GEMM)
     if (rows > 128 && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
-        for (int r0 = 0; r0 < rows; r0 += 128) {
-            const int nr = std::min(128, rows - r0);
+        // (the row-streaming kernel takes 128 rows with the two-way split, 96 with the three-way split)
+        const int step = approx ? 128 : 96;
+        for (int r0 = 0; r0 < rows; r0 += step) {
+            const int nr = std::min(step, rows - r0);
             const size_t o = (size_t)r0 * F_;
             product(X + o, nr, G, alpha, out + o, E1 ? E1 + o : nullptr, b1, E2 ? E2 + o : nullptr, b2, approx);
         }

@@ -22,10 +22,7 @@ namespace dlco {
 
 namespace {
 
-constexpr int JT = 512;
-constexpr int JW = JT / 64;
 constexpr int LP = 8;                 // lanes per column pair
-constexpr int NG = JT / LP;           // pairs in flight
 constexpr int JACOBI_LDS_MAX_N = 192;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -66,10 +63,13 @@ __device__ __forceinline__ void rotation(float a, float b, float c, float &t, fl
 }
 
 // G: column-major, column j at G + j*ldc (ldc multiple of 4, entries [n, ldc) are zero)
+// JT threads: JT / 8 pairs in flight (512: up to n = 128 in one pass per round; 1024: up to n = 256)
+template <int JT>
 __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
                             float *scratch /* >= 4n floats, global */, int *sweeps_out, float *red /* LDS, JW+4 */,
                             float *nrm /* n floats, LDS or global */, float stop_cos)
 {
+    constexpr int JW = JT / 64, NG = JT / LP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- shift: sigma = 1.01 * max_i sum_j |T_ij| + tiny  (Gershgorin) ------------------------
@@ -217,20 +217,22 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
     }
 }
 
+template <int JT>
 __global__ __launch_bounds__(JT) void jacobi_lds_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
                                                         long ldv, float *scratch, int *sweeps_out, float stop_cos)
 {
     extern __shared__ __attribute__((aligned(16))) float sh[];
-    float *G = sh, *red = sh + (size_t)n * ldc, *nrm = red + JW + 4;
-    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm, stop_cos);
+    float *G = sh, *red = sh + (size_t)n * ldc, *nrm = red + JT / 64 + 4;
+    jacobi_body<JT>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm, stop_cos);
 }
 
+template <int JT>
 __global__ __launch_bounds__(JT) void jacobi_gmem_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
                                                          long ldv, float *work, int *sweeps_out, float stop_cos)
 {
-    __shared__ float red[JW + 4];
+    __shared__ float red[JT / 64 + 4];
     float *G = work, *scratch = work + (size_t)n * ldc;
-    jacobi_body(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos);
+    jacobi_body<JT>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos);
 }
 
 // ---- n <= 128: one column pair per 16 lanes ------------------------------------------------------
@@ -587,16 +589,23 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         else if (e == 3) hipLaunchKernelGGL(jacobi16_kernel<3>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
         else hipLaunchKernelGGL(jacobi16_kernel<4>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
     } else if (n <= JACOBI_LDS_MAX_N) {
-        const size_t lds = ((size_t)n * ldc + JW + 4 + n + 4) * sizeof(float);
+        // 8 lanes per pair: 512 threads cover 64 pairs per pass, 1024 threads 128 (n > 128: one pass per round)
+        const bool wide = n > 128;
+        const size_t lds = ((size_t)n * ldc + (wide ? 16 : 8) + 4 + n + 4) * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel),
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<512>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<1024>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(JT), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        if (wide) hipLaunchKernelGGL(jacobi_lds_kernel<1024>, dim3(1), dim3(1024), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        else hipLaunchKernelGGL(jacobi_lds_kernel<512>, dim3(1), dim3(512), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+    } else if (n <= 256) {
+        hipLaunchKernelGGL(jacobi_gmem_kernel<1024>, dim3(1), dim3(1024), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
     } else {
-        hipLaunchKernelGGL(jacobi_gmem_kernel, dim3(1), dim3(JT), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
     }
     DLCO_HIP(hipGetLastError());
 }

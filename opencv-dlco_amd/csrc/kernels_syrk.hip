@@ -22,6 +22,7 @@ namespace dlco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -56,7 +57,12 @@ union SyrkLds {
 // SLAB = false: the whole symmetric matrix (upper tiles computed, mirrored).
 // SLAB = true : only the tile columns [slab_t0, slab_t0 + slab_nt) of the matrix, all tile rows,
 //               no mirror — the rank's column slab of a dual average that is sharded over GPUs.
-template <bool PAIR, bool SLAB>
+// BF16 = true : the products run on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
+//               rate) with fp32 accumulation: the operands w_k x_k and x_k are rounded to bf16 when the
+//               fragments are read (BASELINE configs[4], "bf16 MFMA + fp32 accum"); everything else -
+//               gather, weights, dual average, stores - stays fp32.  Opt-in (cfg.grad_bf16), gated by the
+//               FPR@95 band in the tests: not the reference's arithmetic.
+template <bool PAIR, bool SLAB, bool BF16>
 __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
@@ -174,6 +180,26 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         if (kt + 1 < nk) load_rows();                         // data of tile kt+1 (ids already here)
         if (kt + 2 < nk) load_ids(kt + 2);                    // ids of tile kt+2
         __builtin_amdgcn_s_setprio(1);
+        if (BF16) {
+            // fragment of the 32x32x16 bf16 MFMA: lane (lr, lk) holds k = 8 lk .. 8 lk + 7 of row lr; the
+            // k-major fp32 image is read with the same conflict-free 4-byte accesses as below
+#pragma unroll
+            for (int ks = 0; ks < KB / 16; ks++) {
+                bf16x8 a0, a1, b0, b1;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 16 * ks + 8 * lk + j;
+                    a0[j] = (__bf16)lds.st.A[buf][k][wm * 64 + lr];
+                    a1[j] = (__bf16)lds.st.A[buf][k][wm * 64 + 32 + lr];
+                    b0[j] = (__bf16)lds.st.B[buf][k][wn * 64 + lr];
+                    b1[j] = (__bf16)lds.st.B[buf][k][wn * 64 + 32 + lr];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < KB / 2; kk++) {
             const float a0 = lds.st.A[buf][2 * kk + lk][wm * 64 + lr];
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 }  // namespace
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
-                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols)
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
     const bool slab = slab_cols > 0;
@@ -254,13 +280,15 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         g.stagger_from = n_cu;
         g.stagger_units = ntiles >= 4 * n_cu ? units : 0;      // only worth it over several rounds of tiles
     }
-    if (slab) {
-        if (ids2) hipLaunchKernelGGL((syrk_rda_kernel<true, true>), dim3(ntiles), dim3(NTH), 0, s, g);
-        else hipLaunchKernelGGL((syrk_rda_kernel<false, true>), dim3(ntiles), dim3(NTH), 0, s, g);
+#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g)
+    if (bf16) {
+        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, true); else DLCO_SYRK_LAUNCH(false, true, true); }
+        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, true); else DLCO_SYRK_LAUNCH(false, false, true); }
     } else {
-        if (ids2) hipLaunchKernelGGL((syrk_rda_kernel<true, false>), dim3(ntiles), dim3(NTH), 0, s, g);
-        else hipLaunchKernelGGL((syrk_rda_kernel<false, false>), dim3(ntiles), dim3(NTH), 0, s, g);
+        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, false); else DLCO_SYRK_LAUNCH(false, true, false); }
+        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, false); else DLCO_SYRK_LAUNCH(false, false, false); }
     }
+#undef DLCO_SYRK_LAUNCH
     DLCO_HIP(hipGetLastError());
     return true;
 }

@@ -725,3 +725,315 @@ void dlco_ref_stats(const dlco_ref_ctx *c, int *dim, float *fpr95, double *auc)
     dlco_ref_roc_stats(dist, c->labels, c->N, fpr95, auc);
     free(nzW); free(dist); free(ids);
 }
+
+
+/* ========================================================================= */
+/* pr-learn: L1-regularised RDA on the pooling-region weight  */
+/* vector w, src/pr-learn.cpp:229-434, and ComputePRStats, src/misc.cpp:171-264 */
+/* ========================================================================= */
+struct dlco_ref_pr {
+    const float   *dists;
+    const uint8_t *labels;
+    int N, F;
+    float mu, gamma;
+    int32_t *idx_pos, *idx_neg;
+    int n_pos, n_neg, n_pos_trn, n_neg_trn;
+    uint64_t rng;              /* RNG rng(2215), src/pr-learn.cpp:241 */
+    unsigned t;
+    float *w, *dfavg, *diff;
+    int32_t last_pos, last_neg;
+    float last_f;
+};
+
+dlco_ref_pr *dlco_ref_pr_create(const float *dists, const uint8_t *labels, int N, int F, float mu, float gamma)
+{
+    dlco_ref_pr *c = (dlco_ref_pr *)calloc(1, sizeof(*c));
+    c->dists = dists; c->labels = labels; c->N = N; c->F = F; c->mu = mu; c->gamma = gamma;
+    c->idx_pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    c->idx_neg = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    /* :229-243: the same index build and randShuffle-on-theRNG() pattern as pj-learn */
+    dlco_ref_build_index(labels, N, c->idx_pos, &c->n_pos, c->idx_neg, &c->n_neg);
+    c->n_pos_trn = (int)dlco_ref_split((size_t)c->n_pos);       /* :251-252 */
+    c->n_neg_trn = (int)dlco_ref_split((size_t)c->n_neg);
+    c->rng = 2215;
+    c->w = (float *)calloc((size_t)F, sizeof(float));           /* :195-196 */
+    c->dfavg = (float *)calloc((size_t)F, sizeof(float));
+    c->diff = (float *)calloc((size_t)F, sizeof(float));
+    return c;
+}
+
+void dlco_ref_pr_destroy(dlco_ref_pr *c)
+{
+    if (!c) return;
+    free(c->idx_pos); free(c->idx_neg); free(c->w); free(c->dfavg); free(c->diff); free(c);
+}
+
+/* One iteration of the loop body at src/pr-learn.cpp:302-329, single-threaded order (with more
+ * than one OpenMP thread the reference draws its samples in thread-arrival order, :306-310, so only
+ * the one-thread order is reproducible).  OpenCV semantics restated [OpenCV-src]:
+ *   gemm(w, FeatDiff, .., GEMM_2_T) on CV_32F accumulates in double and rounds once to float;
+ *   `dfAvg = t * dfAvg / (t + 1)` is a MatExpr scaled by alpha = t * (1.0 / (t + 1)) (double),
+ *     applied by convertTo as float(x * (float)alpha);
+ *   scaleAdd(FeatDiff, 1/(t+1), dfAvg, dfAvg) = FeatDiff * (float)(1.0/(t+1)) + dfAvg in float
+ *     (taken unfused; an FMA build of OpenCV may differ in the last bit);
+ *   `w = -sqrt(t+1)/gamma * (dfAvg + mu)` = dfAvg * (float)a + (float)(mu * a), a in double, unfused;
+ *   max(w, 0).                                                                              */
+void dlco_ref_pr_step(dlco_ref_pr *c)
+{
+    const int F = c->F;
+    const unsigned t = c->t;
+    int ip = dlco_ref_rng_uniform(&c->rng, 0, c->n_pos_trn);
+    int in = dlco_ref_rng_uniform(&c->rng, 0, c->n_neg_trn);
+    const float *xp = c->dists + (size_t)c->idx_pos[ip] * F, *xn = c->dists + (size_t)c->idx_neg[in] * F;
+    c->last_pos = c->idx_pos[ip]; c->last_neg = c->idx_neg[in];
+    double acc = 0.0;
+    for (int k = 0; k < F; k++) {
+        float d = xp[k] - xn[k];                               /* subtract(), :312-314 */
+        c->diff[k] = d;
+        acc += (double)c->w[k] * (double)d;                    /* gemm, :319 */
+    }
+    const float f = (float)acc;
+    c->last_f = f;
+    const float sa = (float)((double)t * (1.0 / ((double)t + 1.0)));         /* :322 */
+    for (int k = 0; k < F; k++) c->dfavg[k] = c->dfavg[k] * sa;
+    if (f > -1.0f) {                                                             /* :324-325 */
+        const float al = (float)(1.0 / ((double)t + 1.0));
+        for (int k = 0; k < F; k++) {
+            volatile float prod = c->diff[k] * al;
+            c->dfavg[k] = prod + c->dfavg[k];
+        }
+    }
+    const double a = -sqrt((double)t + 1.0) / (double)c->gamma;                  /* :328 */
+    const float fa = (float)a, fb = (float)((double)c->mu * a);
+    for (int k = 0; k < F; k++) {
+        volatile float prod = c->dfavg[k] * fa;
+        float v = prod + fb;
+        c->w[k] = v > 0.0f ? v : 0.0f;                                            /* :329 */
+    }
+    c->t = t + 1;
+}
+
+void dlco_ref_pr_steps(dlco_ref_pr *c, unsigned n) { for (unsigned i = 0; i < n; i++) dlco_ref_pr_step(c); }
+
+void dlco_ref_pr_get(const dlco_ref_pr *c, unsigned *t, float *w, float *dfavg, int32_t *last_pos, int32_t *last_neg, float *last_f)
+{
+    if (t) *t = c->t;
+    if (w) memcpy(w, c->w, sizeof(float) * (size_t)c->F);
+    if (dfavg) memcpy(dfavg, c->dfavg, sizeof(float) * (size_t)c->F);
+    if (last_pos) *last_pos = c->last_pos;
+    if (last_neg) *last_neg = c->last_neg;
+    if (last_f) *last_f = c->last_f;
+}
+
+void dlco_ref_pr_set(dlco_ref_pr *c, unsigned t, const float *w, const float *dfavg)
+{
+    c->t = t;
+    if (w) memcpy(c->w, w, sizeof(float) * (size_t)c->F);
+    if (dfavg) memcpy(c->dfavg, dfavg, sizeof(float) * (size_t)c->F);
+}
+
+/* dist[i] = w . x_i (float accumulation in index order: cuda::gemm / cuBLAS order is unspecified,
+ * src/pr-learn.cpp:343-344; CPU gemm of ComputePRStats accumulates in double, src/misc.cpp:226) */
+static void pr_gemv(const float *w, const float *D, const int32_t *ids, int n, int F, float *out, int in_double)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        const float *x = D + (size_t)(ids ? ids[i] : i) * F;
+        if (in_double) {
+            double s = 0.0;
+            for (int k = 0; k < F; k++) s += (double)w[k] * (double)x[k];
+            out[i] = (float)s;
+        } else {
+            float s = 0.0f;
+            for (int k = 0; k < F; k++) s += w[k] * x[k];
+            out[i] = s;
+        }
+    }
+}
+
+/* src/pr-learn.cpp:340-361: validation loss, regulariser mu * sum|w|, NNZ */
+void dlco_ref_pr_validate(const dlco_ref_pr *c, float *loss_val, float *regul, int *nnz)
+{
+    int npv = c->n_pos - c->n_pos_trn, nnv = c->n_neg - c->n_neg_trn;
+    float *pdv = (float *)malloc(sizeof(float) * (size_t)(npv > 0 ? npv : 1));
+    float *ndv = (float *)malloc(sizeof(float) * (size_t)(nnv > 0 ? nnv : 1));
+    pr_gemv(c->w, c->dists, c->idx_pos + c->n_pos_trn, npv, c->F, pdv, 0);
+    pr_gemv(c->w, c->dists, c->idx_neg + c->n_neg_trn, nnv, c->F, ndv, 0);
+    float Loss = (float)dlco_ref_hinge_sum(pdv, npv, ndv, nnv);                  /* :348-351 */
+    *loss_val = Loss / (float)((size_t)npv * (size_t)nnv);                       /* :355 */
+    double s = 0.0; int nz = 0;
+    for (int k = 0; k < c->F; k++) { s += fabs((double)c->w[k]); nz += c->w[k] != 0.0f; }
+    *regul = (float)((double)c->mu * s);                                         /* :358 */
+    if (nnz) *nnz = nz;
+    free(pdv); free(ndv);
+}
+
+/* ComputePRStats, src/misc.cpp:171-264.  PRParams [8*F, pr_cols]; returns Dim > MaxDim early like
+ * the reference when max_dim != -1 (fpr95/auc untouched).                                     */
+void dlco_ref_pr_stats(const float *prparams, int pr_cols, const float *dists, const uint8_t *labels, int N, int F,
+                       const float *w, int nchannels, int max_dim, int *nPR, int *Dim, int *nzDim, float *fpr95, double *auc)
+{
+    /* rows of PRParams selected by w > 0 that have a non-zero entry (:183-193) */
+    int cap = 8 * F, nsel = 0;
+    const float **sel = (const float **)malloc(sizeof(float *) * (size_t)cap);
+    for (int i = 0; i < F; i++)
+        for (int j = 0; j < 8; j++) {
+            const float *row = prparams + (size_t)(i * 8 + j) * pr_cols;
+            if (!(w[i] > 0.0f)) continue;
+            int any = 0;
+            for (int k = 0; k < pr_cols; k++) any |= row[k] != 0.0f;
+            if (any) sel[nsel++] = row;
+        }
+    /* rows that have an identical twin elsewhere (:196-213); nPR = nzDim - dup/2 */
+    int dup = 0;
+    for (int i = 0; i < nsel; i++) {
+        int inside = 0;
+        for (int j = 0; j < nsel && !inside; j++) {
+            if (i == j) continue;
+            int same = 1;
+            for (int k = 0; k < pr_cols && same; k++) same = sel[i][k] == sel[j][k];
+            inside = same;
+        }
+        dup += inside;
+    }
+    free(sel);
+    *nzDim = nsel;
+    *nPR = nsel - dup / 2;
+    *Dim = *nPR * nchannels;
+    if (max_dim != -1 && *Dim > max_dim) return;
+    float *pd = (float *)malloc(sizeof(float) * (size_t)N);
+    pr_gemv(w, dists, NULL, N, F, pd, 1);                                        /* :226 */
+    dlco_ref_roc_stats(pd, labels, N, fpr95, auc);                               /* :227-263, same sweep as the PJ stage */
+    free(pd);
+}
+
+
+/* ========================================================================= */
+/* Descriptor generation: get_desc, src/vgg-desc.cpp:41-152,  */
+/* and the per-pair loop of comp-uprjdists, src/comp-uprjdists.cpp:298-349     */
+/* ========================================================================= */
+/* OpenCV primitives restated [OpenCV-src] (parity unpinned against a live build):
+ *   GaussianBlur(Size(0,0), sigma) on CV_32F: ksize = cvRound(sigma*4*2 + 1) | 1; kernel
+ *     cf[i] = (float)exp(-0.5/sigma^2 * x^2), normalised by the float sum's reciprocal (double);
+ *     separable, float intermediate, BORDER_REPLICATE; the row pass adds the taps left to right,
+ *     the column pass in symmetric form k0*c + sum_k k_k*(up_k + down_k);
+ *   filter2D with [-1 0 1]: right neighbour minus left neighbour, BORDER_REPLICATE;
+ *   magnitude: sqrtf(x*x + y*y), products and sum in float, not fused;
+ *   `GAngle / AngleStep - 0.5f` and `GMag /= s`: MatExpr scalings by (float)(1.0 / s) in float;
+ *   cv::sort ascending; mquantiles(alphap = betap = 0.5) as written at :113-130.                  */
+#define DESC_P 64                 /* patch edge */
+#define DESC_NPIX (DESC_P * DESC_P)
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int cmp_float_asc(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* PatchTrans [4096][nAngleBins] (row p = x*64 + y: the reference transposes before filling, :136-150) */
+void dlco_ref_get_desc(const uint8_t *patch, int nAngleBins, float InitSigma, int bNorm, float *PatchTrans)
+{
+    enum { P = DESC_P, NP = DESC_NPIX };
+    static const double kPi = 3.1415926535897932384626433832795;        /* CV_PI */
+    float *img = (float *)malloc(sizeof(float) * NP), *tmp = (float *)malloc(sizeof(float) * NP);
+    float *mag = (float *)malloc(sizeof(float) * NP), *ratio = (float *)malloc(sizeof(float) * NP);
+    for (int i = 0; i < NP; i++) img[i] = (float)patch[i];                /* convertTo CV_32F, :44 */
+    /* ---- GaussianBlur, :46 ---- */
+    int ks = (int)lrint((double)InitSigma * 4.0 * 2.0 + 1.0) | 1;
+    if (ks > 63) ks = 63;
+    float cf[64];
+    {
+        double scale2x = -0.5 / ((double)InitSigma * (double)InitSigma), sum = 0.0;
+        for (int i = 0; i < ks; i++) {
+            double x = i - (ks - 1) * 0.5;
+            cf[i] = (float)exp(scale2x * x * x);
+            sum += cf[i];
+        }
+        sum = 1.0 / sum;
+        for (int i = 0; i < ks; i++) cf[i] = (float)(cf[i] * sum);
+    }
+    const int r = ks / 2;
+    for (int y = 0; y < P; y++)
+        for (int x = 0; x < P; x++) {
+            float s = cf[0] * img[y * P + clampi(x - r, 0, P - 1)];
+            for (int k = 1; k < ks; k++) { volatile float pr = cf[k] * img[y * P + clampi(x - r + k, 0, P - 1)]; s += pr; }
+            tmp[y * P + x] = s;
+        }
+    for (int y = 0; y < P; y++)
+        for (int x = 0; x < P; x++) {
+            float s = cf[r] * tmp[y * P + x];
+            for (int k = 1; k <= r; k++) {
+                volatile float pair = tmp[clampi(y - k, 0, P - 1) * P + x] + tmp[clampi(y + k, 0, P - 1) * P + x];
+                volatile float pr = cf[r + k] * pair;
+                s += pr;
+            }
+            img[y * P + x] = s;
+        }
+    /* ---- gradient, magnitude, orientation ratio, :48-70 ---- */
+    const float AngleStep = (float)(2.0f * kPi / (double)(float)nAngleBins);
+    const float inv_step = (float)(1.0 / (double)AngleStep);
+    for (int y = 0; y < P; y++)
+        for (int x = 0; x < P; x++) {
+            float ix = img[y * P + clampi(x + 1, 0, P - 1)] - img[y * P + clampi(x - 1, 0, P - 1)];
+            float iy = img[clampi(y + 1, 0, P - 1) * P + x] - img[clampi(y - 1, 0, P - 1) * P + x];
+            volatile float xx = ix * ix, yy = iy * iy;
+            mag[y * P + x] = sqrtf(xx + yy);
+            float ang = (float)((double)atan2f(iy, ix) + kPi);
+            volatile float sc = ang * inv_step;
+            ratio[y * P + x] = sc - 0.5f;
+        }
+    /* ---- quantile normalisation, :106-133 ---- */
+    if (bNorm) {
+        memcpy(tmp, mag, sizeof(float) * NP);
+        qsort(tmp, NP, sizeof(float), cmp_float_asc);
+        const int n = NP;
+        float aleph = (float)n * 0.8f + 0.5f;
+        int k = (int)floorf(aleph);
+        if (k >= n - 1) k = n - 1;
+        if (k <= 1) k = 1;
+        float gamma = aleph - (float)k;
+        if (gamma >= 1.0f) gamma = 1.0f;
+        if (gamma <= 0.0f) gamma = 0.0f;
+        volatile float t1 = (1.0f - gamma) * tmp[k - 1], t2 = gamma * tmp[k];
+        float T = t1 + t2;
+        if (T != 0.0f) {
+            const float sc = (float)(1.0 / (double)(T / (float)nAngleBins));
+            for (int i = 0; i < NP; i++) mag[i] = mag[i] * sc;
+        }
+    }
+    /* ---- soft assignment into the transposed layout, :72-104,136-150 ---- */
+    memset(PatchTrans, 0, sizeof(float) * (size_t)NP * nAngleBins);
+    for (int y = 0; y < P; y++)
+        for (int x = 0; x < P; x++) {
+            const float rt = ratio[y * P + x];
+            const float off = rt - floorf(rt);
+            int b1 = (ceilf(rt - 1.0f) == -1.0f) ? nAngleBins - 1 : (int)(unsigned char)ceilf(rt - 1.0f);
+            int b2 = (b1 + 1 > nAngleBins - 1) ? 0 : b1 + 1;
+            const int p = x * P + y;                           /* .t() */
+            const float m = mag[y * P + x];
+            if (b1 >= 0 && b1 < nAngleBins) PatchTrans[(size_t)p * nAngleBins + b1] = (1.0f - off) * m;
+            if (b2 >= 0 && b2 < nAngleBins) PatchTrans[(size_t)p * nAngleBins + b2] = off * m;
+        }
+    free(img); free(tmp); free(mag); free(ratio);
+}
+
+/* Desc = min(sPRFilters [nsel,4096] * PatchTrans [4096,8], 1), row-major [nsel*8]
+ * (src/comp-uprjdists.cpp:320-325; cv::gemm accumulates in double for CV_32F)                    */
+void dlco_ref_patch_descriptor(const uint8_t *patch, const float *sPR, int nsel, float *desc)
+{
+    enum { NB = 8 };
+    float *pt = (float *)malloc(sizeof(float) * (size_t)DESC_NPIX * NB);
+    dlco_ref_get_desc(patch, NB, 1.4f, 1, pt);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nsel; i++) {
+        double acc[NB] = {0};
+        const float *f = sPR + (size_t)i * DESC_NPIX;
+        for (int p = 0; p < DESC_NPIX; p++) {
+            if (f[p] == 0.0f) continue;
+            for (int b = 0; b < NB; b++) acc[b] += (double)f[p] * (double)pt[(size_t)p * NB + b];
+        }
+        for (int b = 0; b < NB; b++) { float v = (float)acc[b]; desc[(size_t)i * NB + b] = v < 1.0f ? v : 1.0f; }
+    }
+    free(pt);
+}

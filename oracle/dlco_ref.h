@@ -151,6 +151,27 @@ void dlco_ref_validate(const dlco_ref_ctx *c, float *loss_val, float *regul);
 /* src/misc.cpp:266-333 on the ctx's data and current W                      */
 void dlco_ref_stats(const dlco_ref_ctx *c, int *dim, float *fpr95, double *auc);
 
+/* ---- pr-learn: src/pr-learn.cpp:229-434, src/misc.cpp:171-264 ---------------
+ * L1-regularised dual averaging on the pooling-region weight vector w [F]: one (positive, negative)
+ * row pair per iteration, in the reference's single-thread order (see dlco_ref.c for the OpenCV
+ * semantics that are restated, parity unpinned like the PJ stage).                            */
+typedef struct dlco_ref_pr dlco_ref_pr;
+dlco_ref_pr *dlco_ref_pr_create(const float *dists, const uint8_t *labels, int N, int F, float mu, float gamma);
+void dlco_ref_pr_destroy(dlco_ref_pr *c);
+void dlco_ref_pr_step(dlco_ref_pr *c);
+void dlco_ref_pr_steps(dlco_ref_pr *c, unsigned n);
+void dlco_ref_pr_get(const dlco_ref_pr *c, unsigned *t, float *w, float *dfavg, int32_t *last_pos, int32_t *last_neg, float *last_f);
+void dlco_ref_pr_set(dlco_ref_pr *c, unsigned t, const float *w, const float *dfavg);
+void dlco_ref_pr_validate(const dlco_ref_pr *c, float *loss_val, float *regul, int *nnz);
+void dlco_ref_pr_stats(const float *prparams, int pr_cols, const float *dists, const uint8_t *labels, int N, int F,
+                       const float *w, int nchannels, int max_dim, int *nPR, int *Dim, int *nzDim, float *fpr95, double *auc);
+
+/* ---- descriptor generation: src/vgg-desc.cpp:41-152, src/comp-uprjdists.cpp:298-349 ----
+ * get_desc on one 64 x 64 u8 patch -> PatchTrans [4096][nAngleBins]; and the pooled descriptor
+ * min(sPRFilters * PatchTrans, 1) [nsel*8] that comp-uprjdists differences per pair.                */
+void dlco_ref_get_desc(const uint8_t *patch, int nAngleBins, float InitSigma, int bNorm, float *PatchTrans);
+void dlco_ref_patch_descriptor(const uint8_t *patch, const float *sPR, int nsel, float *desc);
+
 #ifdef __cplusplus
 }
 #endif

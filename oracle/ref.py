@@ -104,6 +104,17 @@ def lib():
                                      c_i32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dlco_ref_validate.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.dlco_ref_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    L.dlco_ref_pr_create.argtypes = [c_f32p, c_u8p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.dlco_ref_pr_create.restype = C.c_void_p
+    L.dlco_ref_pr_destroy.argtypes = [C.c_void_p]
+    L.dlco_ref_pr_steps.argtypes = [C.c_void_p, C.c_uint]
+    L.dlco_ref_pr_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint), c_f32p, c_f32p, c_i32p, c_i32p, c_f32p]
+    L.dlco_ref_pr_set.argtypes = [C.c_void_p, C.c_uint, c_f32p, c_f32p]
+    L.dlco_ref_pr_validate.argtypes = [C.c_void_p, c_f32p, c_f32p, c_i32p]
+    L.dlco_ref_pr_stats.argtypes = [c_f32p, C.c_int, c_f32p, c_u8p, C.c_int, C.c_int, c_f32p, C.c_int, C.c_int,
+                                    c_i32p, c_i32p, c_i32p, c_f32p, c_f64p]
+    L.dlco_ref_get_desc.argtypes = [c_u8p, C.c_int, C.c_float, C.c_int, c_f32p]
+    L.dlco_ref_patch_descriptor.argtypes = [c_u8p, c_f32p, C.c_int, c_f32p]
     ob = find_openblas()
     if ob:
         L.dlco_ref_load_blas(ob.encode())
@@ -352,3 +363,71 @@ class Trainer:
         d, f, a = C.c_int(), C.c_float(), C.c_double()
         lib().dlco_ref_stats(self._h, C.byref(d), C.byref(f), C.byref(a))
         return d.value, float(f.value), float(a.value)
+
+
+class PrTrainer:
+    """The reference's pr-learn loop (src/pr-learn.cpp:229-434), single-thread order."""
+
+    def __init__(self, dists, labels, mu=0.025, gamma=0.10):
+        self.dists = np.ascontiguousarray(dists, np.float32)
+        self.labels = np.ascontiguousarray(labels, np.uint8).ravel()
+        self.N, self.F = self.dists.shape
+        self._h = lib().dlco_ref_pr_create(_p(self.dists, c_f32p), _p(self.labels, c_u8p), self.N, self.F, mu, gamma)
+
+    def close(self):
+        if self._h:
+            lib().dlco_ref_pr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def steps(self, n):
+        lib().dlco_ref_pr_steps(self._h, n)
+
+    def state(self):
+        t = C.c_uint()
+        w, df = np.empty(self.F, np.float32), np.empty(self.F, np.float32)
+        lp, ln, lf = C.c_int32(), C.c_int32(), C.c_float()
+        lib().dlco_ref_pr_get(self._h, C.byref(t), _p(w, c_f32p), _p(df, c_f32p), C.byref(lp), C.byref(ln), C.byref(lf))
+        return dict(t=t.value, w=w, dfavg=df, last_pos=lp.value, last_neg=ln.value, last_f=lf.value)
+
+    def set_state(self, t, w=None, dfavg=None):
+        w = None if w is None else np.ascontiguousarray(w, np.float32)
+        d = None if dfavg is None else np.ascontiguousarray(dfavg, np.float32)
+        lib().dlco_ref_pr_set(self._h, t, _p(w, c_f32p), _p(d, c_f32p))
+
+    def validate(self):
+        lo, rg, nz = C.c_float(), C.c_float(), C.c_int32()
+        lib().dlco_ref_pr_validate(self._h, C.byref(lo), C.byref(rg), C.byref(nz))
+        return float(lo.value), float(rg.value), nz.value
+
+    def stats(self, prparams, w=None, nchannels=8, max_dim=-1):
+        p = np.ascontiguousarray(prparams, np.float32)
+        w = self.state()["w"] if w is None else np.ascontiguousarray(w, np.float32)
+        npr, dim, nz, f, a = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float(-1.0), C.c_double(0.0)
+        lib().dlco_ref_pr_stats(_p(p, c_f32p), p.shape[1], _p(self.dists, c_f32p), _p(self.labels, c_u8p), self.N, self.F,
+                                _p(w, c_f32p), nchannels, max_dim, C.byref(npr), C.byref(dim), C.byref(nz), C.byref(f), C.byref(a))
+        return dict(nPR=npr.value, dim=dim.value, nzdim=nz.value, fpr95=float(f.value), auc=float(a.value))
+
+
+def get_desc(patch, n_angle_bins=8, init_sigma=1.4, norm=True):
+    """get_desc (src/vgg-desc.cpp:41-152): 64x64 u8 patch -> PatchTrans [4096, n_angle_bins]."""
+    p = np.ascontiguousarray(patch, np.uint8)
+    assert p.shape == (64, 64)
+    out = np.empty((4096, n_angle_bins), np.float32)
+    lib().dlco_ref_get_desc(_p(p, c_u8p), n_angle_bins, init_sigma, 1 if norm else 0, _p(out, c_f32p))
+    return out
+
+
+def patch_descriptor(patch, sPR):
+    """min(sPRFilters * get_desc(patch), 1) flattened row-major [nsel*8] (src/comp-uprjdists.cpp:317-325)."""
+    p = np.ascontiguousarray(patch, np.uint8)
+    f = np.ascontiguousarray(sPR, np.float32)
+    assert p.shape == (64, 64) and f.shape[1] == 4096
+    out = np.empty(f.shape[0] * 8, np.float32)
+    lib().dlco_ref_patch_descriptor(_p(p, c_u8p), _p(f, c_f32p), f.shape[0], _p(out, c_f32p))
+    return out

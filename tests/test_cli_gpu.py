@@ -144,3 +144,51 @@ def test_pj_learn_multi_process_failure_exits_nonzero(tools, dataset, tmp_path):
     assert "rank 1" in p.stderr
     q = subprocess.run([pj, src, str(tmp_path / "bad"), "-gpus", "2", "-batch", "41"], capture_output=True, text=True, timeout=60)
     assert q.returncode == 1 and "Usage:" in q.stdout
+
+
+def test_pr_learn_cli_grammar_and_saved_rows(tmp_path):
+    """pr-learn: flags, usage, the Best/Stat/Step grammar of src/pr-learn.cpp:366-403 (scraped by
+    workspace/05-prstats.sh) and the rows appended to the "w" dataset, one per "[saved]" line."""
+    subprocess.check_call(["make", "-s", "-C", CLI])
+    pr = os.path.join(CLI, "pr-learn")
+    p = subprocess.run([pr, "only", "two"], capture_output=True, text=True)
+    assert p.returncode == 1 and "Usage: pr-learn  src_h5_filter_file" in p.stdout
+    N, F = 3000, 256
+    rng = np.random.default_rng(4)
+    L = (np.arange(N) % 2 == 0).astype(np.uint8)
+    D = rng.random((N, F)).astype(np.float32)
+    D[:, :24] *= np.where(L[:, None] == 1, 0.25, 1.0).astype(np.float32)
+    P = rng.integers(0, 6, (8 * F, 3)).astype(np.float32)
+    flt, src = tmp_path / "filters", tmp_path / "fulldists"
+    flt.mkdir(); src.mkdir()
+    np.save(flt / "PRParams.npy", P)
+    np.save(flt / "RingParams.npy", np.zeros((5, 3), np.float32))
+    np.save(src / "Distance.npy", D)
+    np.save(src / "Label.npy", L.reshape(-1, 1))
+    for dst in (str(tmp_path / "out"), str(tmp_path / "out.h5")):
+        if dst.endswith(".h5") and not os.path.exists("/opt/conda/lib/libhdf5.so"):
+            continue
+        q = subprocess.run([pr, str(flt), str(src), dst, "-mu", "0.03", "-gamma", "0.25", "-iters", "20000", "-logstep", "4000", "-maxdim", "400"],
+                           capture_output=True, text=True, timeout=600)
+        assert q.returncode == 0, q.stderr
+        lines = q.stdout.splitlines()
+        assert lines[0] == "mu: 0.03 gamma: 0.25 maxdim: 400 nIters: 20000"
+        assert lines[1] == "Load PRParams." and lines[2] == "Load RingParams."
+        assert lines[3] == "Load Labels: 3000" and lines[4] == "Load Distances: 3000 x 256"
+        body = [l for l in lines if l.startswith(("Best: ", "Step: ", "Stat: "))]
+        ts = [int(re.split(r"[ :]+", l)[1]) for l in body if l.startswith(("Best: ", "Step: "))]
+        assert ts == [4000, 8000, 12000, 16000, 20000]
+        best = re.compile(r"^Best: \d+  Loss: \d+\.\d{6} Regul: \d+\.\d{6} Obj: \d+\.\d{6} \(\d+\.\d{6}\)  NNZ: \d+ \(\d+\)  Ttime: \d+\.\d{4} Vtime: \d+\.\d{4}$")
+        stat = re.compile(r"^Stat: nPR #\d+ \(#\d+\) Dim/MaxDim \[\d+/400\] AUC: \d\.\d{6} FPR95: \d+\.\d{2}( \[saved\])?$")
+        step = re.compile(r"^Step: \d+  Loss: \d+\.\d{6} Regul: \d+\.\d{6} Obj: \d+\.\d{6} \(\d+\.\d{6}\)  NNZ: \d+ \(\d+\)  Ttime: \d+\.\d{4} Vtime: \d+\.\d{4}$")
+        for i, l in enumerate(body):
+            assert best.match(l) or stat.match(l) or step.match(l), l
+            if l.startswith("Best: "):
+                assert stat.match(body[i + 1])
+        nsaved = sum(l.endswith("[saved]") for l in body)
+        if not dst.endswith(".h5"):
+            assert nsaved >= 1
+            W = np.load(dst + "/w.npy")
+            assert W.shape == (nsaved, F) and (W >= 0).all() and (W != 0).any()
+        else:
+            assert os.path.getsize(dst) > 0

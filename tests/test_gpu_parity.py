@@ -587,3 +587,49 @@ def test_strict_conv_surfaces_a_missed_tolerance(dlco):
     assert err.value.code == dlco.ERR_NOCONV
     assert strict.t() >= 1                                  # the step itself was applied
     strict.close()
+
+
+def test_grad_rda_bf16_variant(dlco, ref):
+    """cfg.grad_bf16 (BASELINE configs[4]): the SYRK's operands are rounded to bf16 (8 significant bits)
+    when the MFMA fragments are read, accumulation stays fp32.  Error budget vs fp64: each product carries
+    ~2^-8 relative error of random sign, so the sum over K rows stays within 1e-2 of the largest entry;
+    the exact fp32 path is 5e-6.  Symmetry (mirrored store) is exact in both."""
+    F, N, B = 256, 1500, 200
+    D, L = synth(N, F, k=10, seed=3)
+    rng = np.random.default_rng(1)
+    pr, nr = rng.integers(0, N, B).astype(np.int32), rng.integers(0, N, B).astype(np.int32)
+    rho, kap = rng.integers(0, 40, B).astype(np.int32), rng.integers(0, 40, B).astype(np.int32)
+    want = ref.grad_reform(D[pr], D[nr], rho, kap, f64=True)
+    got = {}
+    for mode in (0, 1):
+        ctx = dlco.Context(F, N, B=B, grad_bf16=mode)
+        ctx.set_data(D, L)
+        got[mode] = ctx.grad_rda(pr, nr, rho, kap, 1.0, 0.0, None)
+        ctx.close()
+        assert np.array_equal(got[mode], got[mode].T)
+    assert relmax(got[0], want) <= TOL_GRAD
+    e16 = relmax(got[1], want)
+    assert 1e-6 < e16 <= 1e-2, e16                       # really the bf16 path, and inside its budget
+
+
+def test_bf16_variant_keeps_the_fpr95_band(dlco):
+    """The gate of the bf16 variant is the metric's, not the fp32 tolerances: two free-running
+    trainers (exact fp32 / bf16 gradient) on BASELINE configs[0]'s shape end at the same operating point
+    within three standard errors of an FPR@95 estimate and the same rank +-3."""
+    N, F, B = 5000, 512, 200
+    D, L = synth(N, F, k=40, seed=2215, sp=0.8, noise=0.25)
+    out = []
+    for mode in (0, 1):
+        ctx = dlco.Context(F, N, B=B, mu=0.004, gamma=0.5, grad_bf16=mode)
+        ctx.set_data(D, L)
+        ctx.steps(300)
+        lo, rg, rank = ctx.validate()
+        _, f95, auc = ctx.stats()
+        out.append((lo, rg, rank, f95, auc))
+        assert ctx.counters()["nonconverged"] == 0
+        ctx.close()
+    (lo0, rg0, r0, f0, a0), (lo1, rg1, r1, f1, a1) = out
+    se = float(np.sqrt(max(f0 * (1.0 - f0), 1e-6) / int((L == 0).sum())))
+    assert 0.01 <= f0 <= 0.2
+    assert abs(f1 - f0) <= max(1e-3, 3.0 * se) and abs(a1 - a0) <= 3e-3 and abs(r1 - r0) <= 3
+    assert abs(lo1 - lo0) <= 0.05 * lo0 + 1e-4 and abs(rg1 - rg0) <= 0.05 * rg0 + 1e-4
