@@ -129,10 +129,28 @@ def pmc_traffic(F, bl):
 
 
 def ncores():
+    """Threads the CPU baseline may use: the affinity mask, cut to the cgroup's CPU quota when one is set
+    (more threads than the quota only get throttled) and to DLCO_CPU_THREADS when given."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = max(1, min(n, int(-(-float(quota) // period))))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("DLCO_CPU_THREADS")
+    if env:
+        n = max(1, min(n, int(env)))
+    return n
 
 
 def cpu_baseline(ctx, wl, rows, steps, t0_step):

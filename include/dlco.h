@@ -95,6 +95,9 @@ int dlco_set_data_device(dlco_ctx *ctx, const float *dists_dev, const uint8_t *l
  * subtraction); Label[i] = (pairs[i][1] == pairs[i][3]), src/comp-uprjdists.cpp:268-272.
  * Every result is bit-identical to dlco_set_data on the pre-differenced matrix. */
 int dlco_set_pairs(dlco_ctx *ctx, const float *desc_host, int32_t P, const int32_t *pairs_host);
+/* same with the descriptor table already in device memory (e.g. written by dlco_desc_compute_device);
+ * the caller keeps it alive for the life of the context */
+int dlco_set_pairs_device(dlco_ctx *ctx, const float *desc_dev, int32_t P, const int32_t *pairs_host);
 /* Bench helper (no reference counterpart: the Brown/Winder sets are not redistributable):
  * fills the context's Distance matrix in HBM with d = U^T z + noise*eps clipped to [-1,1],
  * z ~ N(0, (sigma * s_i)^2 I_k), s_i = exp(scale_jitter * g_i) a per-row log-normal scale (0 = none),
@@ -297,6 +300,37 @@ int dlco_pr_validate(dlco_pr_ctx *ctx, float *loss_val, float *regul, int32_t *n
  * max_dim != -1 and Dim > max_dim the function returns before the ROC pass (fpr95 / auc untouched). */
 int dlco_pr_stats(dlco_pr_ctx *ctx, const float *w_host, const float *prparams_host, int32_t pr_rows, int32_t pr_cols,
                   int32_t nchannels, int32_t max_dim, int32_t *nPR, int32_t *dim, int32_t *nzdim, float *fpr95, double *auc);
+
+/* ===========================================================================================
+ * Descriptor generation — comp-uprjdists: the producer of pj-learn's input.
+ * Replaces get_desc (src/vgg-desc.cpp:41-152), SelectPRFilters (src/misc.cpp:78-168) and the
+ * per-pair loop of src/comp-uprjdists.cpp:298-349.  Descriptors are computed once per PATCH
+ * (the reference recomputes both patches of every pair) and can stay in HBM for the trainer's
+ * pair mode (dlco_set_pairs_device).
+ * =========================================================================================== */
+typedef struct dlco_desc_ctx dlco_desc_ctx;
+
+/* InitSigma / nAngleBins / bNorm of src/comp-uprjdists.cpp:64-68 (1.4, 8, true); nAngleBins must be 8 */
+int  dlco_desc_create(dlco_desc_ctx **out, float init_sigma, int32_t n_angle_bins, int32_t norm, int32_t device);
+void dlco_desc_destroy(dlco_desc_ctx *ctx);
+const char *dlco_desc_last_error(const dlco_desc_ctx *ctx);
+/* SelectPRFilters: rows of pr_filters [8*wcols, cols] with w > 0 that are not all zero, unique,
+ * ascending.  out [nsel, cols] may be NULL to query *nsel_out.  Host logic, no device needed. */
+int  dlco_desc_select_filters(const float *pr_filters, int32_t rows, int32_t cols, const float *w, int32_t wcols,
+                              float *out, int32_t *nsel_out);
+/* sPRFilters [nsel, 4096], columns in the reference's order (pixel x*64+y of the transposed patch) */
+int  dlco_desc_set_filters(dlco_desc_ctx *ctx, const float *filters_host, int32_t nsel);
+int32_t dlco_desc_size(const dlco_desc_ctx *ctx);                         /* nsel * 8 */
+/* get_desc of one 64x64 u8 patch: PatchTrans [4096][8] in the reference's layout */
+int  dlco_desc_transform(dlco_desc_ctx *ctx, const uint8_t *patch_host, float *patch_trans_host);
+/* Desc [n, nsel*8] = min(sPRFilters * get_desc(patch), 1), one row per patch [n,64,64] u8 */
+int  dlco_desc_compute(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n, float *desc_host);
+int  dlco_desc_compute_device(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n, float *desc_dev, int64_t ld);
+/* Distance [n_pairs, nsel*8] and Label [n_pairs] (may be NULL) for pairs [n_pairs,4] =
+ * (patchID1, 3DpointID1, patchID2, 3DpointID2): the two datasets comp-uprjdists writes */
+int  dlco_desc_pair_dists(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                          int64_t n_pairs, float *dist_host, uint8_t *label_host);
+double dlco_desc_last_kernel_ms(const dlco_desc_ctx *ctx);               /* HIP-event time of the last compute call */
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,23 @@ def load():
     L.dlco_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.dlco_eig_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32p]
     L.dlco_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    i64 = C.c_int64
+    L.dlco_set_pairs_device.argtypes = [vp, vp, C.c_int32, i32p]
+    L.dlco_desc_last_error.restype = C.c_char_p
+    L.dlco_desc_last_error.argtypes = [vp]
+    L.dlco_desc_create.argtypes = [C.POINTER(vp), C.c_float, C.c_int32, C.c_int32, C.c_int32]
+    L.dlco_desc_destroy.argtypes = [vp]
+    L.dlco_desc_destroy.restype = None
+    L.dlco_desc_select_filters.argtypes = [f32p, C.c_int32, C.c_int32, f32p, C.c_int32, f32p, C.POINTER(C.c_int32)]
+    L.dlco_desc_set_filters.argtypes = [vp, f32p, C.c_int32]
+    L.dlco_desc_size.argtypes = [vp]
+    L.dlco_desc_size.restype = C.c_int32
+    L.dlco_desc_transform.argtypes = [vp, u8p, f32p]
+    L.dlco_desc_compute.argtypes = [vp, u8p, i64, f32p]
+    L.dlco_desc_compute_device.argtypes = [vp, u8p, i64, vp, i64]
+    L.dlco_desc_pair_dists.argtypes = [vp, u8p, i64, i32p, i64, f32p, u8p]
+    L.dlco_desc_last_kernel_ms.argtypes = [vp]
+    L.dlco_desc_last_kernel_ms.restype = C.c_double
     L.dlco_pr_last_error.restype = C.c_char_p
     L.dlco_pr_last_error.argtypes = [vp]
     L.dlco_pr_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32]
@@ -226,6 +243,12 @@ class Context:
         d, q = _f32(desc), _i32(pairs)
         assert d.ndim == 2 and d.shape[1] == self.F and q.shape == (self.N, 4)
         self._ck(self.L.dlco_set_pairs(self.h, _p(d, f32p), d.shape[0], _p(q, i32p)))
+
+    def set_pairs_device(self, desc_dev_ptr, P, pairs):
+        """Pair mode on a descriptor table that already lives in device memory (dlco_set_pairs_device)."""
+        q = _i32(pairs)
+        assert q.shape == (self.N, 4)
+        self._ck(self.L.dlco_set_pairs_device(self.h, C.c_void_p(desc_dev_ptr), P, _p(q, i32p)))
 
     def synth_data(self, U, seed, sigma_pos, sigma_neg, noise, scale_jitter=0.0):
         U = _f32(U)
@@ -484,3 +507,84 @@ class PrContext:
         self._ck(self.L.dlco_pr_stats(self.h, _p(wv, f32p), _p(p, f32p), p.shape[0], p.shape[1], nchannels, max_dim,
                                       C.byref(npr), C.byref(dim), C.byref(nz), C.byref(f), C.byref(a)))
         return dict(nPR=npr.value, dim=dim.value, nzdim=nz.value, fpr95=f.value, auc=a.value)
+
+
+def select_filters(pr_filters, w):
+    """SelectPRFilters (src/misc.cpp:78-168): host logic of the library, no device needed."""
+    L = load()
+    f, wv = _f32(pr_filters), _f32(w).ravel()
+    assert f.ndim == 2 and f.shape[0] == 8 * wv.size
+    n = C.c_int32()
+    rc = L.dlco_desc_select_filters(_p(f, f32p), f.shape[0], f.shape[1], _p(wv, f32p), wv.size, None, C.byref(n))
+    if rc != OK:
+        raise DlcoError(rc, "dlco_desc_select_filters")
+    out = np.empty((n.value, f.shape[1]), np.float32)
+    if n.value:
+        L.dlco_desc_select_filters(_p(f, f32p), f.shape[0], f.shape[1], _p(wv, f32p), wv.size, _p(out, f32p), C.byref(n))
+    return out
+
+
+class DescContext:
+    """comp-uprjdists on the GPU: get_desc + pooling product per patch (thin wrapper over dlco_desc_ctx)."""
+
+    def __init__(self, init_sigma=1.4, n_angle_bins=8, norm=True, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.dlco_desc_create(C.byref(h), init_sigma, n_angle_bins, 1 if norm else 0, device)
+        if rc != OK:
+            raise DlcoError(rc, self.L.dlco_desc_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dlco_desc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise DlcoError(rc, self.L.dlco_desc_last_error(self.h).decode())
+
+    def set_filters(self, sPR):
+        f = _f32(sPR)
+        assert f.ndim == 2 and f.shape[1] == 4096
+        self._ck(self.L.dlco_desc_set_filters(self.h, _p(f, f32p), f.shape[0]))
+
+    @property
+    def size(self):
+        return self.L.dlco_desc_size(self.h)
+
+    def transform(self, patch):
+        p = np.ascontiguousarray(patch, np.uint8)
+        assert p.shape == (64, 64)
+        out = np.empty((4096, 8), np.float32)
+        self._ck(self.L.dlco_desc_transform(self.h, _p(p, u8p), _p(out, f32p)))
+        return out
+
+    def compute(self, patches):
+        p = np.ascontiguousarray(patches, np.uint8)
+        assert p.ndim == 3 and p.shape[1:] == (64, 64)
+        out = np.empty((p.shape[0], self.size), np.float32)
+        self._ck(self.L.dlco_desc_compute(self.h, _p(p, u8p), p.shape[0], _p(out, f32p)))
+        return out
+
+    def compute_device(self, patches, dev_ptr, ld=None):
+        p = np.ascontiguousarray(patches, np.uint8)
+        assert p.ndim == 3 and p.shape[1:] == (64, 64)
+        self._ck(self.L.dlco_desc_compute_device(self.h, _p(p, u8p), p.shape[0], C.c_void_p(dev_ptr), ld or self.size))
+
+    def pair_dists(self, patches, pairs):
+        p, q = np.ascontiguousarray(patches, np.uint8), _i32(pairs)
+        assert p.ndim == 3 and p.shape[1:] == (64, 64) and q.ndim == 2 and q.shape[1] == 4
+        dist = np.empty((q.shape[0], self.size), np.float32)
+        lab = np.empty(q.shape[0], np.uint8)
+        self._ck(self.L.dlco_desc_pair_dists(self.h, _p(p, u8p), p.shape[0], _p(q, i32p), q.shape[0], _p(dist, f32p), _p(lab, u8p)))
+        return dist, lab
+
+    def last_kernel_ms(self):
+        return self.L.dlco_desc_last_kernel_ms(self.h)

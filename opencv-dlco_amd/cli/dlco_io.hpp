@@ -48,7 +48,7 @@ struct H5 {
     int (*H5Sclose)(hid_t) = nullptr;
     int (*H5Lexists)(hid_t, const char *, hid_t) = nullptr;
     int (*H5Eset_auto2)(hid_t, void *, void *) = nullptr;
-    hid_t native_float = -1, native_uchar = -1;
+    hid_t native_float = -1, native_uchar = -1, native_int = -1;
 
     bool load()
     {
@@ -79,8 +79,9 @@ struct H5 {
         H5Eset_auto2(0, nullptr, nullptr);
         hid_t *pf = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_FLOAT_g"));
         hid_t *pu = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_UCHAR_g"));
-        if (!pf || !pu) return false;
-        native_float = *pf; native_uchar = *pu;
+        hid_t *pi = reinterpret_cast<hid_t *>(dlsym(h, "H5T_NATIVE_INT_g"));
+        if (!pf || !pu || !pi) return false;
+        native_float = *pf; native_uchar = *pu; native_int = *pi;
         return true;
     }
 };
@@ -146,11 +147,15 @@ inline void npy_read(const std::string &path, const char *want_descr, size_t ele
 }
 
 // ---------------------------------------------------------------------------------- datasets
-// Reads dataset `name` as f32 (or u8) into `out`; shape receives its dimensions.
+template <typename T> struct ElemType;
+template <> struct ElemType<float>   { static const char *npy() { return "<f4"; } static H5::hid_t h5t(H5 &L) { return L.native_float; } };
+template <> struct ElemType<uint8_t> { static const char *npy() { return "|u1"; } static H5::hid_t h5t(H5 &L) { return L.native_uchar; } };
+template <> struct ElemType<int32_t> { static const char *npy() { return "<i4"; } static H5::hid_t h5t(H5 &L) { return L.native_int; } };
+
+// Reads dataset `name` as f32, u8 or i32 into `out`; shape receives its dimensions.
 template <typename T>
 void read_dataset(const std::string &path, const char *name, std::vector<size_t> &shape, std::vector<T> &out)
 {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 1, "f32 or u8 only");
     if (is_h5(path)) {
         H5 &L = h5();
         if (!L.load()) throw std::runtime_error("HDF5 input requested but libhdf5 could not be loaded (set DLCO_HDF5_LIB, or pass a directory of .npy files)");
@@ -165,12 +170,12 @@ void read_dataset(const std::string &path, const char *name, std::vector<size_t>
         size_t n = 1;
         for (size_t v : shape) n *= v;
         out.resize(n);
-        const int rc = L.H5Dread(d, sizeof(T) == 4 ? L.native_float : L.native_uchar, 0, 0, 0, out.data());
+        const int rc = L.H5Dread(d, ElemType<T>::h5t(L), 0, 0, 0, out.data());
         L.H5Sclose(s); L.H5Dclose(d); L.H5Fclose(f);
         if (rc < 0) throw std::runtime_error(path + ": read of " + name + " failed");
     } else {
         std::vector<char> bytes;
-        npy_read(path + "/" + name + ".npy", sizeof(T) == 4 ? "<f4" : "|u1", sizeof(T), shape, bytes);
+        npy_read(path + "/" + name + ".npy", ElemType<T>::npy(), sizeof(T), shape, bytes);
         out.resize(bytes.size() / sizeof(T));
         std::memcpy(out.data(), bytes.data(), bytes.size());
     }
@@ -190,21 +195,23 @@ struct Writer {
             mkdir(path.c_str(), 0777);
         }
     }
-    void write_f32(const char *name, const float *data, size_t rows, size_t cols)
+    template <typename T>
+    void write(const char *name, const T *data, size_t rows, size_t cols)
     {
         if (is_h5(path)) {
             H5 &L = h5();
             const unsigned long long dims[2] = {rows, cols};
             const H5::hid_t s = L.H5Screate_simple(2, dims, nullptr);
-            const H5::hid_t d = L.H5Dcreate2(f, name, L.native_float, s, 0, 0, 0);
+            const H5::hid_t d = L.H5Dcreate2(f, name, ElemType<T>::h5t(L), s, 0, 0, 0);
             if (d < 0) throw std::runtime_error(path + ": cannot create dataset " + name);
-            const int rc = (rows != 0 && cols != 0) ? L.H5Dwrite(d, L.native_float, 0, 0, 0, data) : 0;
+            const int rc = (rows != 0 && cols != 0) ? L.H5Dwrite(d, ElemType<T>::h5t(L), 0, 0, 0, data) : 0;
             L.H5Dclose(d); L.H5Sclose(s);
             if (rc < 0) throw std::runtime_error(path + ": write of dataset " + name + " failed");
         } else {
-            npy_write(path + "/" + name + ".npy", data, "<f4", 4, {rows, cols});
+            npy_write(path + "/" + name + ".npy", data, ElemType<T>::npy(), sizeof(T), {rows, cols});
         }
     }
+    void write_f32(const char *name, const float *data, size_t rows, size_t cols) { write<float>(name, data, rows, cols); }
     ~Writer() { if (f >= 0) h5().H5Fclose(f); }
 };
 

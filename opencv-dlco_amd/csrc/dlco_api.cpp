@@ -556,7 +556,19 @@ int dlco_set_data(dlco_ctx *c, const float *dists_host, const uint8_t *labels_ho
 // Pair mode: the caller hands over the P per-patch descriptors and the [N,4] pair table
 // (patchID1, 3DpointID1, patchID2, 3DpointID2: src/comp-uprjdists.cpp:268-269,308-314) instead of
 // the N x F matrix of differences that comp-uprjdists writes to the "Distance" dataset.
+static int set_pairs(dlco_ctx *c, const float *desc, bool desc_on_device, int32_t P, const int32_t *pairs_host);
+
 int dlco_set_pairs(dlco_ctx *c, const float *desc_host, int32_t P, const int32_t *pairs_host)
+{
+    return set_pairs(c, desc_host, false, P, pairs_host);
+}
+
+int dlco_set_pairs_device(dlco_ctx *c, const float *desc_dev, int32_t P, const int32_t *pairs_host)
+{
+    return set_pairs(c, desc_dev, true, P, pairs_host);
+}
+
+static int set_pairs(dlco_ctx *c, const float *desc_host, bool desc_on_device, int32_t P, const int32_t *pairs_host)
 {
     if (!c || !desc_host || !pairs_host || P < 1) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
@@ -569,9 +581,13 @@ int dlco_set_pairs(dlco_ctx *c, const float *desc_host, int32_t P, const int32_t
             a[i] = q[0]; b[i] = q[2];
             lab[i] = (q[1] == q[3]) ? 1 : 0;                       // src/comp-uprjdists.cpp:268-272
         }
-        c->dists_own.alloc((size_t)P * c->F);
-        h2d(c, c->dists_own.p, desc_host, (size_t)P * c->F * sizeof(float));
-        c->dists = c->dists_own.p;
+        if (desc_on_device) {
+            c->dists = desc_host;
+        } else {
+            c->dists_own.alloc((size_t)P * c->F);
+            h2d(c, c->dists_own.p, desc_host, (size_t)P * c->F * sizeof(float));
+            c->dists = c->dists_own.p;
+        }
         c->pair_a.alloc(c->N); c->pair_b.alloc(c->N);
         h2d(c, c->pair_a.p, a.data(), (size_t)c->N * sizeof(int32_t));
         h2d(c, c->pair_b.p, b.data(), (size_t)c->N * sizeof(int32_t));

@@ -447,17 +447,35 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         n_ritz = m_;
         nw = 0;
         while (nw < m_ && h_theta_[nw] > mu) nw++;
+        // What has to be small is the error of A = c * (G - mu)_+, not every Ritz pair by itself.  The
+        // Ritz pairs of the block are exact eigenpairs of G + E with E = -sum_i (r_i q_i^T + q_i r_i^T),
+        // r_i orthogonal to the block, and the derivative of the matrix function (x - mu)_+ damps the
+        // component of E that couples a pair at theta_i > mu with a direction at lambda < mu by the
+        // divided difference (theta_i - mu) / (theta_i - lambda) <= (theta_i - mu) / (theta_i - b), b
+        // the top of the spectrum outside the converged part of the block (taken at the middle guard):
+        // a pair just above the threshold carries almost no weight in A and its residual counts with
+        // that weight.  Pairs well above mu keep the weight 1 of the plain residual test.
         float crit = 0.f;
-        for (int i = 0; i < nw; i++) crit = std::max(crit, cscale * h_res_[i]);
+        const float bsep = (weighted_crit_ && nw < m_) ? std::min(mu, h_theta_[nw + (m_ - nw) / 2]) : mu;
+        for (int i = 0; i < nw; i++) {
+            float wgt = 1.f;
+            const float den = h_theta_[i] - bsep;
+            if (weighted_crit_ && den > 0.f) wgt = std::min(1.f, (h_theta_[i] - mu + h_res_[i]) / den);
+            crit = std::max(crit, cscale * h_res_[i] * wgt);
+        }
         const float emax = nw > 0 ? cscale * (h_theta_[0] - mu) : 0.f;
         last_crit_ = emax > 0.f ? crit / emax : 0.f;
-        // the leading guards must be resolved too, or an eigenvalue just above mu can hide in them:
-        // each needs theta + |r| < mu (no eigenvalue of that pair's interval reaches mu) or a small residual
+        // the leading guards must be resolved too, or an eigenvalue just above mu can hide in them: each
+        // needs theta + |r| < mu (no eigenvalue of that pair's interval reaches mu), or an interval that
+        // reaches above mu by less than the tolerance (what could hide there weighs less than that in A),
+        // or a small residual
         bool guards_ok = true;
         const int ng = std::min(m_, nw + std::max(2, guard_ / 4));
+        const float gtol = tol_ * std::max(emax, cscale * 1e-3f * std::fabs(mu));
         for (int i = nw; i < ng; i++) {
-            const bool below = h_theta_[i] + h_res_[i] < mu;
-            const bool small = cscale * h_res_[i] <= tol_ * std::max(emax, cscale * 1e-3f * std::fabs(mu));
+            const float excess = h_theta_[i] + h_res_[i] - mu;
+            const bool below = excess < 0.f || (weighted_crit_ && cscale * excess <= gtol);
+            const bool small = cscale * h_res_[i] <= gtol;
             guards_ok = guards_ok && (below || small);
         }
         if (m_ >= F_) conv = true;                                   // dense: Rayleigh-Ritz is exact

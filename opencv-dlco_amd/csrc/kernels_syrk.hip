@@ -255,6 +255,274 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming form (default).  In the kernel above a tile is an MFMA phase followed by an HBM phase, and
+// because every tile is alike the whole chip runs the two phases in lock-step: the matrix cores idle
+// while 512 KiB of dfAvg per tile move, HBM idles during the K loops (measured: launch time = MFMA
+// time + HBM time, MFMA busy 46 %).  Here ONE persistent workgroup per CU walks its list of tiles and
+// its waves are specialised:
+//   waves 0-7  (compute)  MFMA from LDS only, each a 64 x 32 part of the tile; at the end of a K loop
+//                         they leave the raw accumulators in an LDS image T of the tile
+//   waves 8-11 (stream)   all memory traffic: the gather of the next K block into the staging images,
+//                         and - spread over the K loop of the NEXT tile, 1/nk of the rows per K block -
+//                         the dual-average update of the tile in T: load old dfAvg, out = alpha*T +
+//                         beta*old, store the rows (waves 8-9) and the mirrored 16-byte pieces (10-11)
+// so the dfAvg stream of tile n runs under the MFMA work of tile n+1.  Arithmetic, K order and the
+// mirror rule on diagonal tiles are those of the kernel above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST = 768;
+constexpr int SCW = 8;            // compute waves
+
+struct SyrkLds2 {
+    float A[2][KB][LD];
+    float B[2][KB][LD];
+    float T[TB][TLD];
+};                                 // 135,168 B: one workgroup per CU
+
+struct TileRef { int i0, j0; bool diag; };
+
+// Dual-average update of the tile held in T, in row groups of 4 rows (32 per tile).
+// role 0: whole rows (s = 0..127: row s>>5 of the group, 16-byte column piece s&31); role 1: the
+// mirrored copy (s = column jl; the group's four rows are 16 contiguous bytes of the mirrored row).
+__device__ __forceinline__ f32x4 syrk_old_load(const SyrkDev &g, TileRef tr, int role, int s, int gq)
+{
+    if (role == 0) return *reinterpret_cast<const f32x4 *>(&g.C[(long)(tr.i0 + 4 * gq + (s >> 5)) * g.ldc + tr.j0 + 4 * (s & 31)]);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = g.C[(long)(tr.i0 + 4 * gq + e) * g.ldc + tr.j0 + s];
+    return v;
+}
+
+template <bool SLAB>
+__device__ __forceinline__ void syrk_apply(const SyrkDev &g, const float (*T)[TLD], TileRef tr, int role, int s, int gq, f32x4 old)
+{
+    if (role == 0) {
+        const int row = 4 * gq + (s >> 5), c4 = 4 * (s & 31);
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(&T[row][c4]);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = fmaf(g.alpha, t4[e], g.beta * old[e]);
+        float *dst = &g.C[(long)(tr.i0 + row) * g.ldc + tr.j0 + c4];
+        if (SLAB || !tr.diag) *reinterpret_cast<f32x4 *>(dst) = o;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (c4 + e >= row) dst[e] = o[e];                      // upper triangle of a diagonal tile
+        }
+    } else if (!SLAB) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = fmaf(g.alpha, T[4 * gq + e][s], g.beta * old[e]);
+        float *dst = &g.C[(long)(tr.j0 + s) * g.ldc + tr.i0 + 4 * gq];
+        if (!tr.diag) *reinterpret_cast<f32x4 *>(dst) = o;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (4 * gq + e < s) dst[e] = o[e];                     // the lower triangle mirrors the upper one
+        }
+    }
+}
+
+// groups g0, g0+gs, .. < g1, loads and stores back to back (tails, and the flush of the last tile)
+template <bool SLAB>
+__device__ __forceinline__ void syrk_drain(const SyrkDev &g, const float (*T)[TLD], TileRef tr, int role, int s, int g0, int g1, int gs,
+                                           bool use_old)
+{
+    for (int gb = g0; gb < g1; gb += 2 * gs) {
+        f32x4 old[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            old[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gb + u * gs < g1 && use_old) old[u] = syrk_old_load(g, tr, role, s, gb + u * gs);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (gb + u * gs < g1) syrk_apply<SLAB>(g, T, tr, role, s, gb + u * gs, old[u]);
+    }
+}
+
+template <bool PAIR, bool SLAB, bool BF16>
+__global__ __launch_bounds__(ST) void syrk_rda_stream_kernel(SyrkDev g)
+{
+    __shared__ __attribute__((aligned(16))) SyrkLds2 lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool streamer = wave >= SCW;
+    const int sid = tid - SCW * 64;                            // 0..255 in the stream waves
+    const int lr = lane & 31, lk = lane >> 5;
+    const int wm = (wave >> 2) & 1, wn = wave & 3;             // compute wave: rows wm*64.., columns wn*32..
+
+    // tile list: the XCD's contiguous chunk of the tile enumeration, dealt round-robin to its workgroups
+    const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    const int nxcd = 8, per = gridDim.x / nxcd;
+    const int xcd = blockIdx.x % nxcd, within = blockIdx.x / nxcd;
+    const int q = ntiles / nxcd, r = ntiles % nxcd;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, len = q + (xcd < r ? 1 : 0);
+
+    const int kact = min(*g.k_dev, g.kmax);
+    const int nk = (kact + KB - 1) / KB;
+    const bool use_old = (g.beta != 0.f);
+
+    const int c4 = sid & 31, rbase = (sid >> 5) & 7;           // gather mapping of the stream threads
+    int32_t id_nx[4], id2_nx[4];
+    float w_nx[4];
+    f32x4 ra[4], rb[4];
+    bool have_prev = false;
+    TileRef prev{0, 0, false};
+    // share of the stream threads in a tile's update: waves 8-9 the rows, 10-11 the mirrored pieces (column-slab
+    // mode has no mirror: both halves take rows, alternate groups)
+    constexpr int SPF = SLAB ? 2 : 4;                          // row groups whose old values are prefetched per K block
+    const int d_role = SLAB ? 0 : (sid >> 7) & 1, d_s = sid & 127;
+    const int d_g0 = SLAB ? (sid >> 7) & 1 : 0, d_gs = SLAB ? 2 : 1;
+    f32x4 old_nx[SPF];
+#pragma unroll
+    for (int u = 0; u < SPF; u++) old_nx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tl = within; tl < len; tl += per) {
+        const int t = start + tl;
+        int bi, bj;
+        if (SLAB) {
+            bi = t / g.slab_nt;
+            bj = g.slab_t0 + t % g.slab_nt;
+        } else {
+            float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
+            bi = max(0, min(g.nt - 1, (int)fb));
+            while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
+            while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
+            bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
+        }
+        const int i0 = bi * TB, j0 = bj * TB;
+
+        auto load_ids = [&](int kt) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = kt * KB + rbase + 8 * u;
+                id_nx[u] = g.ids[k];
+                if (PAIR) id2_nx[u] = g.ids2[k];
+                w_nx[u] = g.w[k];
+            }
+        };
+        auto load_rows = [&]() {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float *row = g.D + (long)id_nx[u] * g.ldd;
+                f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
+                f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
+                if (PAIR) {
+                    const float *row2 = g.D + (long)id2_nx[u] * g.ldd;
+                    xa -= *reinterpret_cast<const f32x4 *>(row2 + i0 + c4 * 4);
+                    xb -= *reinterpret_cast<const f32x4 *>(row2 + j0 + c4 * 4);
+                }
+                ra[u] = xa * w_nx[u];
+                rb[u] = xb;
+            }
+        };
+        auto store_rows = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                *reinterpret_cast<f32x4 *>(&lds.A[buf][rbase + 8 * u][c4 * 4]) = ra[u];
+                *reinterpret_cast<f32x4 *>(&lds.B[buf][rbase + 8 * u][c4 * 4]) = rb[u];
+            }
+        };
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[a][e] = 0.f;
+
+        if (streamer && nk > 0) {
+            load_ids(0);
+            load_rows();
+            if (nk > 1) load_ids(1);
+            if (have_prev && use_old) {                        // old values of the first share of the previous tile
+                const int nb = 32 / nk;
+#pragma unroll
+                for (int u = 0; u < SPF; u++) {
+                    const int gq = d_g0 + u * d_gs;
+                    if (gq < nb) old_nx[u] = syrk_old_load(g, prev, d_role, d_s, gq);
+                }
+            }
+            store_rows(0);
+        }
+        __syncthreads();                                       // staging image 0 ready; T of the previous tile complete
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            if (streamer) {
+                if (kt + 1 < nk) load_rows();
+                if (kt + 2 < nk) load_ids(kt + 2);
+                if (have_prev) {
+                    // this K block's share of the previous tile: its old values were requested one K block ago
+                    const int ga = (kt * 32) / nk, gb = ((kt + 1) * 32) / nk;
+#pragma unroll
+                    for (int u = 0; u < SPF; u++) {
+                        const int gq = ga + d_g0 + u * d_gs;
+                        if (gq < gb) syrk_apply<SLAB>(g, lds.T, prev, d_role, d_s, gq, old_nx[u]);
+                    }
+                    if (ga + d_g0 + SPF * d_gs < gb) syrk_drain<SLAB>(g, lds.T, prev, d_role, d_s, ga + d_g0 + SPF * d_gs, gb, d_gs, use_old);
+                    if (kt + 1 < nk && use_old) {
+                        const int na = ((kt + 1) * 32) / nk, nb = ((kt + 2) * 32) / nk;
+#pragma unroll
+                        for (int u = 0; u < SPF; u++) {
+                            const int gq = na + d_g0 + u * d_gs;
+                            if (gq < nb) old_nx[u] = syrk_old_load(g, prev, d_role, d_s, gq);
+                        }
+                    }
+                }
+                if (kt + 1 < nk) store_rows(buf ^ 1);
+            } else {
+                __builtin_amdgcn_s_setprio(1);
+                if (BF16) {
+#pragma unroll
+                    for (int ks = 0; ks < KB / 16; ks++) {
+                        bf16x8 a0, a1, b0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int k = 16 * ks + 8 * lk + j;
+                            a0[j] = (__bf16)lds.A[buf][k][wm * 64 + lr];
+                            a1[j] = (__bf16)lds.A[buf][k][wm * 64 + 32 + lr];
+                            b0[j] = (__bf16)lds.B[buf][k][wn * 32 + lr];
+                        }
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll 8
+                    for (int kk = 0; kk < KB / 2; kk++) {
+                        const float a0 = lds.A[buf][2 * kk + lk][wm * 64 + lr];
+                        const float a1 = lds.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
+                        const float b0 = lds.B[buf][2 * kk + lk][wn * 32 + lr];
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+        if (nk == 0) {                                         // no active row: the tiles only decay (out = beta * old)
+            if (have_prev && streamer) syrk_drain<SLAB>(g, lds.T, prev, d_role, d_s, d_g0, 32, d_gs, use_old);
+            __syncthreads();
+        }
+        if (!streamer) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    lds.T[wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk][wn * 32 + lr] = acc[a][e];
+        }
+        have_prev = true;
+        prev = TileRef{i0, j0, bi == bj};
+    }
+    __syncthreads();
+    if (have_prev) {
+        // the last tile: all twelve waves stream it out
+        const int pair = wave >> 1, s = tid & 127;
+        if (SLAB) syrk_drain<SLAB>(g, lds.T, prev, 0, s, pair, 32, 6, use_old);
+        else syrk_drain<SLAB>(g, lds.T, prev, pair & 1, s, pair >> 1, 32, 3, use_old);
+    }
+}
+
 }  // namespace
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
@@ -280,7 +548,24 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         g.stagger_from = n_cu;
         g.stagger_units = ntiles >= 4 * n_cu ? units : 0;      // only worth it over several rounds of tiles
     }
-#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g)
+    static const bool use_v1 = std::getenv("DLCO_SYRK_V1") != nullptr;
+    int n_wg = 256;
+    {
+        int dev = 0; hipDeviceProp_t prop;
+        static int n_cu_s = 0;
+        if (n_cu_s == 0) {
+            DLCO_HIP(hipGetDevice(&dev));
+            DLCO_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu_s = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        n_wg = std::max(8, n_cu_s / 8 * 8);
+        n_wg = std::min(n_wg, (ntiles + 7) / 8 * 8);
+    }
+#define DLCO_SYRK_LAUNCH(P, S, H)                                                                              \
+    do {                                                                                                       \
+        if (use_v1) hipLaunchKernelGGL((syrk_rda_kernel<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g);          \
+        else hipLaunchKernelGGL((syrk_rda_stream_kernel<P, S, H>), dim3(n_wg), dim3(ST), 0, s, g);             \
+    } while (0)
     if (bf16) {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, true); else DLCO_SYRK_LAUNCH(false, true, true); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, true); else DLCO_SYRK_LAUNCH(false, false, true); }

@@ -979,7 +979,10 @@ void dlco_ref_get_desc(const uint8_t *patch, int nAngleBins, float InitSigma, in
             float iy = img[clampi(y + 1, 0, P - 1) * P + x] - img[clampi(y - 1, 0, P - 1) * P + x];
             volatile float xx = ix * ix, yy = iy * iy;
             mag[y * P + x] = sqrtf(xx + yy);
-            float ang = (float)((double)atan2f(iy, ix) + kPi);
+            /* atan2 on floats rounded to float: taken from the double routine, whose rounding to float is the
+             * correctly rounded single result (glibc 2.35's atan2f itself is only accurate to < 1 ulp)       */
+            float at = (float)atan2((double)iy, (double)ix);
+            float ang = (float)((double)at + kPi);
             volatile float sc = ang * inv_step;
             ratio[y * P + x] = sc - 0.5f;
         }

@@ -431,3 +431,42 @@ def patch_descriptor(patch, sPR):
     out = np.empty(f.shape[0] * 8, np.float32)
     lib().dlco_ref_patch_descriptor(_p(p, c_u8p), _p(f, c_f32p), f.shape[0], _p(out, c_f32p))
     return out
+
+
+def select_pr_filters(pr_filters, w):
+    """SelectPRFilters restated loop for loop (src/misc.cpp:78-168): keep rows whose w entry is positive and
+    that have a non-zero, drop repeats (first occurrence stays), then the reference's insertion sort."""
+    f = np.ascontiguousarray(pr_filters, np.float32)
+    wv = np.asarray(w, np.float32).ravel()
+    assert wv.size * 8 == f.shape[0]
+    kept = [f[i * 8 + j] for i in range(wv.size) for j in range(8)
+            if wv[i] > 0.0 and np.count_nonzero(f[i * 8 + j]) != 0]                 # :89-100
+    uniq = []
+    for r in kept:                                                                    # :104-122
+        if not any(np.array_equal(r, u) for u in uniq):
+            uniq.append(r)
+    if not uniq:
+        return np.empty((0, f.shape[1]), np.float32)
+    s = np.zeros((len(uniq), f.shape[1]), np.float32)
+    s[0] = uniq[0]
+    for i in range(1, len(uniq)):                                                     # :127-165
+        idx = i
+        while idx > 0:
+            cmp = False
+            for j in range(f.shape[1]):
+                if uniq[i][j] == s[idx - 1][j]:
+                    continue
+                if uniq[i][j] < s[idx - 1][j]:
+                    cmp = True
+                    s[idx] = s[idx - 1]
+                else:
+                    cmp = False
+                    s[idx] = uniq[i]
+                break
+            if cmp:
+                idx -= 1
+                if idx == 0:
+                    s[idx] = uniq[i]
+                continue
+            break
+    return s

@@ -168,18 +168,18 @@ def test_pr_learn_cli_grammar_and_saved_rows(tmp_path):
     for dst in (str(tmp_path / "out"), str(tmp_path / "out.h5")):
         if dst.endswith(".h5") and not os.path.exists("/opt/conda/lib/libhdf5.so"):
             continue
-        q = subprocess.run([pr, str(flt), str(src), dst, "-mu", "0.03", "-gamma", "0.25", "-iters", "20000", "-logstep", "4000", "-maxdim", "400"],
+        q = subprocess.run([pr, str(flt), str(src), dst, "-mu", "0.03", "-gamma", "0.25", "-iters", "20000", "-logstep", "4000", "-maxdim", "100000"],
                            capture_output=True, text=True, timeout=600)
         assert q.returncode == 0, q.stderr
         lines = q.stdout.splitlines()
-        assert lines[0] == "mu: 0.03 gamma: 0.25 maxdim: 400 nIters: 20000"
+        assert lines[0] == "mu: 0.03 gamma: 0.25 maxdim: 100000 nIters: 20000"
         assert lines[1] == "Load PRParams." and lines[2] == "Load RingParams."
         assert lines[3] == "Load Labels: 3000" and lines[4] == "Load Distances: 3000 x 256"
         body = [l for l in lines if l.startswith(("Best: ", "Step: ", "Stat: "))]
         ts = [int(re.split(r"[ :]+", l)[1]) for l in body if l.startswith(("Best: ", "Step: "))]
         assert ts == [4000, 8000, 12000, 16000, 20000]
         best = re.compile(r"^Best: \d+  Loss: \d+\.\d{6} Regul: \d+\.\d{6} Obj: \d+\.\d{6} \(\d+\.\d{6}\)  NNZ: \d+ \(\d+\)  Ttime: \d+\.\d{4} Vtime: \d+\.\d{4}$")
-        stat = re.compile(r"^Stat: nPR #\d+ \(#\d+\) Dim/MaxDim \[\d+/400\] AUC: \d\.\d{6} FPR95: \d+\.\d{2}( \[saved\])?$")
+        stat = re.compile(r"^Stat: nPR #\d+ \(#\d+\) Dim/MaxDim \[\d+/100000\] AUC: \d\.\d{6} FPR95: \d+\.\d{2}( \[saved\])?$")
         step = re.compile(r"^Step: \d+  Loss: \d+\.\d{6} Regul: \d+\.\d{6} Obj: \d+\.\d{6} \(\d+\.\d{6}\)  NNZ: \d+ \(\d+\)  Ttime: \d+\.\d{4} Vtime: \d+\.\d{4}$")
         for i, l in enumerate(body):
             assert best.match(l) or stat.match(l) or step.match(l), l
@@ -192,3 +192,53 @@ def test_pr_learn_cli_grammar_and_saved_rows(tmp_path):
             assert W.shape == (nsaved, F) and (W >= 0).all() and (W != 0).any()
         else:
             assert os.path.getsize(dst) > 0
+
+
+def test_comp_uprjdists_cli_feeds_pj_learn(tmp_path):
+    """comp-uprjdists: the reference's flags and dataset names (src/comp-uprjdists.cpp:54-133,254-349); its
+    "Distance"/"Label" equal the library's descriptors differenced per pair, and pj-learn trains on them."""
+    import importlib
+    from test_descriptors import make_filters, make_patches
+    dlco = importlib.import_module("opencv-dlco_amd")
+    subprocess.check_call(["make", "-s", "-C", CLI])
+    cu, pj = os.path.join(CLI, "comp-uprjdists"), os.path.join(CLI, "pj-learn")
+    p = subprocess.run([cu, "only"], capture_output=True, text=True)
+    assert p.returncode == 1 and "Usage: comp-uprjdists src_h5_filter_file src_h5_img_file" in p.stdout
+    n, wcols = 120, 6
+    rng = np.random.default_rng(12)
+    patches = make_patches(n, seed=31)
+    PR = np.zeros((wcols * 8, 4096), np.float32)
+    PR[:40] = make_filters(40, seed=3, scale=25.0)
+    PR[5] = PR[4]                                                  # a repeat and all-zero rows (40..47)
+    w = np.array([[0.3, 0.0, 0.2, 0.1, 0.5, 0.7], [0, 0, 0, 0, 0, 1.0]], np.float32)
+    ids = rng.integers(0, 12, n)
+    a, b = rng.integers(0, n, 900), rng.integers(0, n, 900)
+    b[::2] = [rng.choice(np.nonzero(ids == ids[x])[0]) for x in a[::2]]
+    pairs = np.stack([a, ids[a], b, ids[b]], 1).astype(np.int32)
+    flt, img, prj, out = (tmp_path / s for s in ("filters", "images", "prj", "dists"))
+    for d in (flt, img, prj):
+        d.mkdir()
+    np.save(flt / "PRFilters.npy", PR.reshape(-1, 64, 64))
+    np.save(img / "Indices.npy", pairs)
+    np.save(img / "Patches.npy", patches)
+    np.save(prj / "w.npy", w)
+    q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "0", "-out", str(out)], capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr
+    sPR = dlco.select_filters(PR, w[0])
+    assert len(sPR) == 31                                          # 4 columns x 8 rows, minus the repeat
+    assert "PRFilters: 31 x 4096" in q.stdout and "Descriptor size: 248" in q.stdout and "Done." in q.stdout
+    D, L = np.load(out / "Distance.npy"), np.load(out / "Label.npy")
+    ctx = dlco.DescContext()
+    ctx.set_filters(sPR)
+    want, lab = ctx.pair_dists(patches, pairs)
+    assert D.shape == (900, 248) and np.array_equal(D, want)
+    assert L.shape == (900, 1) and np.array_equal(L.ravel(), lab) and 0 < L.sum() < 900
+    # -id picks the row of "w"
+    q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "1", "-out", str(tmp_path / "d1")], capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0 and "Descriptor size: 0" not in q.stdout
+    q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "2", "-out", str(tmp_path / "d2")], capture_output=True, text=True)
+    assert q.returncode == 2 and "no such row" in q.stderr
+    # the next stage of the pipeline reads what this one wrote
+    r = subprocess.run([pj, str(out), str(tmp_path / "model"), "-iters", "40", "-batch", "32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Load Distances: 900 x 248" in r.stdout
