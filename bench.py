@@ -53,10 +53,13 @@ WORKLOADS = {
     # tools/sweep_synth.py picked these (gpurun_out/sweep2.log): rank 64 / FPR95 6.1 % and rank 127 / FPR95 5.6 % at step 520
     "c2": dict(name="configs[1] Liberty-shaped, rank ~64", F=8192, N=500000, batch=200, mu=0.0025, gamma=0.5,
                latent=96, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
-               rank_band=(48, 88), fpr95_band=(0.02, 0.15)),
+               rank_band=(48, 88), fpr95_band=(0.02, 0.15), burn_in=300),
     "c3": dict(name="configs[2] NotreDame-shaped, rank ~128", F=8192, N=500000, batch=200, mu=0.001, gamma=0.5,
                latent=192, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
-               rank_band=(100, 160), fpr95_band=(0.02, 0.15)),
+               # from W = 0 the rank overshoots (789 at step 50) and decays: 166 at step 320, 127 at step 520, 116 at
+               # step 640 (DLCO_EIG_DEBUG trace, gpurun_out/c3_dbg2.err): the named regime, rank ~128, is reached
+               # after ~500 steps, and before that every step still takes 2-3 tracker passes on a block of 192+ rows
+               rank_band=(100, 160), fpr95_band=(0.02, 0.15), burn_in=500),
 }
 
 
@@ -261,9 +264,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE configs[1] (rank ~64, the metric's configuration); c3 = configs[2] (rank ~128)")
-    ap.add_argument("--burn-in", type=int, default=300,
+    ap.add_argument("--burn-in", type=int, default=None,
                     help="full training steps run while the workload is set up, to reach the rank regime the "
-                         "BASELINE configuration names (0 = time the start-up transient)")
+                         "BASELINE configuration names (default: 300 for c2, 500 for c3; 0 = time the start-up transient)")
     ap.add_argument("--F", type=int, default=None)
     ap.add_argument("--N", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="pair-rows per class PER GPU")
@@ -310,6 +313,8 @@ def main():
         if v_ is not None:
             wl[k_] = v_
     F, N, Bl = wl["F"], wl["N"], wl["batch"]
+    if args.burn_in is None:
+        args.burn_in = wl.get("burn_in", 300)
 
     use_dist = world > 1 or args.force_dist
     if args.force_dist:

@@ -828,7 +828,10 @@ int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_set_state: step in flight");
         DLCO_CHECK(r >= 0 && r <= c->w_cap, DLCO_ERR_INVALID, "dlco_set_state: r out of range");
         c->t = t;
-        if (dfavg_host) h2d(c, c->dfavg.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+        if (dfavg_host) {
+            h2d(c, c->dfavg.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+            if (!c->shard) syrk_mirror_upper(c->dfavg.p, c->F, c->F, c->stream);
+        }
         c->eig->reset();
         if (W_host && r > 0) {
             h2d(c, c->W.p, W_host, (size_t)r * c->F * sizeof(float));
@@ -928,8 +931,10 @@ int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_
         h2d(c, rho.p, rho_host, (size_t)B * sizeof(int32_t));
         h2d(c, kap.p, kappa_host, (size_t)B * sizeof(int32_t));
         const size_t FF = (size_t)c->F * c->F;
-        if (dfavg_in_host) h2d(c, c->grad.p, dfavg_in_host, FF * sizeof(float));
-        else fill_f32(c->grad.p, 0.f, FF, c->stream);
+        if (dfavg_in_host) {
+            h2d(c, c->grad.p, dfavg_in_host, FF * sizeof(float));
+            if (!c->shard) syrk_mirror_upper(c->grad.p, c->F, c->F, c->stream);
+        } else fill_f32(c->grad.p, 0.f, FF, c->stream);
         build_active_rows(pr.p, nr.p, rho.p, kap.p, B, 0, B, ids.p, w.p, k.p, c->stream);
         grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, c->grad.p);
         d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));

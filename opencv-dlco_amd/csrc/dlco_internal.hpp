@@ -149,6 +149,9 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
 // ids2 != nullptr (pair mode): row k is D[ids[k]] - D[ids2[k]], formed on the fly.
 // slab_cols > 0 (dual average sharded over GPUs): only the columns [slab_col0, slab_col0 + slab_cols)
 // of C are computed and stored (all rows, no mirror); both must be multiples of 128.
+// lower triangle := upper triangle: the fused SYRK relies on an exactly symmetric dual average (it keeps
+// it so itself); a matrix that comes from outside (dlco_set_state, dlco_grad_rda) is symmetrised first
+void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s);
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
                   int slab_cols = 0, bool bf16 = false);

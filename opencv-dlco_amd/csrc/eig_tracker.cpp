@@ -34,8 +34,8 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     // filter products run on the bf16 matrix cores with split operands unless DLCO_FP32_FILTER is set
     bf16_filter_ = (F_ % 512 == 0) && std::getenv("DLCO_FP32_FILTER") == nullptr;
     if (bf16_filter_) {
-        plane_hi_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
-        plane_lo_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
+        plane_hi_.alloc(bf16x2_plane_bytes(std::min(cap_, 160), F_));
+        plane_lo_.alloc(bf16x2_plane_bytes(std::min(cap_, 160), F_));
         // the Rayleigh-Ritz product takes the three-way split (fp32-level accuracy) unless DLCO_FP32_RR is set
         if (std::getenv("DLCO_FP32_RR") == nullptr) plane_lo2_.alloc(bf16x2_plane_bytes(std::min(cap_, 128), F_));
     }
@@ -105,9 +105,11 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
 {
     // the split-bf16 kernels take up to 128 rows: a taller block goes through them in row chunks
     // (one HBM-bound pass over G per chunk, still cheaper than the generic fp32 GEMM)
-    if (rows > 128 && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
-        // (the row-streaming kernel takes 128 rows with the two-way split, 96 with the three-way split)
-        const int step = approx ? 128 : 96;
+    // (the row-streaming kernel takes 160 rows with the two-way split - a block of rank ~128 plus its guards
+    // in ONE pass over G - and 96 with the three-way split; a sharded rank's slab kernel 128)
+    const int one_pass = (approx && !shard_ && F_ % 512 == 0) ? 160 : 128;
+    if (rows > one_pass && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
+        const int step = approx ? (rows <= 2 * one_pass ? (rows / 2 + 31) / 32 * 32 : one_pass) : 96;
         for (int r0 = 0; r0 < rows; r0 += step) {
             const int nr = std::min(step, rows - r0);
             const size_t o = (size_t)r0 * F_;
@@ -149,7 +151,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         unpack_cols(out, F_, shard_->gather, cw, rows, world, s_);
         return;
     }
-    if (bf16_filter_ && rows <= 128 && F_ >= 256 && (approx || plane_lo2_.p)) {
+    if (bf16_filter_ && rows <= one_pass && F_ >= 256 && (approx || plane_lo2_.p)) {
         // filter products: two-way split (~1e-5); exact products (Rayleigh-Ritz): three-way split (~1e-7)
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         const bool ok = skinny_product_bf16x2(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p,

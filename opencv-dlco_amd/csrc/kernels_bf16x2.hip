@@ -413,7 +413,7 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
 {
     const int mt = (M + 31) / 32;
     const int ks = ksplit > 0 ? ksplit : KS;
-    if (M < 1 || mt > 4 || N % 128 != 0 || K % (16 * ks * 2 * 4) != 0) return false;   // 4 steps per loop trip
+    if (M < 1 || mt > 5 || N % 128 != 0 || K % (16 * ks * 2 * 4) != 0) return false;   // 4 steps per loop trip
     if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) return false;
     const long total = (long)(K / 16) * mt * 64;
     hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, K,
@@ -430,7 +430,7 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
     static const bool rows_ok = std::getenv("DLCO_PRODUCT_V1") == nullptr;
     // (four row tiles with the three-way split do not fit the register budget of the split-role kernel)
     if (rows_ok && N == K && K % (128 * ks) == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0 &&
-        (long)K * ldg * 4 < (1L << 31) && !(mt == 4 && plane_lo2)) {
+        (long)K * ldg * 4 < (1L << 31) && !(mt >= 4 && plane_lo2)) {
         if (plane_lo2) {
             if (mt == 1) launch_rows<1, 3>(g, grid, s);
             else if (mt == 2) launch_rows<2, 3>(g, grid, s);
@@ -440,13 +440,14 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
             if (mt == 1) launch_rows<1, 2>(g, grid, s);
             else if (mt == 2) launch_rows<2, 2>(g, grid, s);
             else if (mt == 3) launch_rows<3, 2>(g, grid, s);
-            else launch_rows<4, 2>(g, grid, s);
+            else if (mt == 4) launch_rows<4, 2>(g, grid, s);
+            else launch_rows<5, 2>(g, grid, s);               // 160 rows: blocks of rank ~128 + guards in ONE pass over G
         }
         DLCO_HIP(hipGetLastError());
         splitk_reduce_f32(slab, ks, M, N, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
         return true;
     }
-    if (g_tiled) return false;                                 // only the row-streaming kernel reads the tiled layout
+    if (g_tiled || mt > 4) return false;                       // only the row-streaming kernel reads the tiled layout / takes five row tiles
     if (plane_lo2) {                                         // three-way split: fp32-level accuracy
         if (mt == 1) hipLaunchKernelGGL((skinny_bf16x2_kernel<1, 3>), grid, block, 0, s, g);
         else if (mt == 2) hipLaunchKernelGGL((skinny_bf16x2_kernel<2, 3>), grid, block, 0, s, g);

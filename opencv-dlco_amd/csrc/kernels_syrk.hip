@@ -257,100 +257,124 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 
 
 // ---------------------------------------------------------------------------------------------------
-// Streaming form (default).  In the kernel above a tile is an MFMA phase followed by an HBM phase, and
-// because every tile is alike the whole chip runs the two phases in lock-step: the matrix cores idle
-// while 512 KiB of dfAvg per tile move, HBM idles during the K loops (measured: launch time = MFMA
-// time + HBM time, MFMA busy 46 %).  Here ONE persistent workgroup per CU walks its list of tiles and
-// its waves are specialised:
-//   waves 0-7  (compute)  MFMA from LDS only, each a 64 x 32 part of the tile; at the end of a K loop
-//                         they leave the raw accumulators in an LDS image T of the tile
-//   waves 8-11 (stream)   all memory traffic: the gather of the next K block into the staging images,
-//                         and - spread over the K loop of the NEXT tile, 1/nk of the rows per K block -
-//                         the dual-average update of the tile in T: load old dfAvg, out = alpha*T +
-//                         beta*old, store the rows (waves 8-9) and the mirrored 16-byte pieces (10-11)
-// so the dfAvg stream of tile n runs under the MFMA work of tile n+1.  Arithmetic, K order and the
-// mirror rule on diagonal tiles are those of the kernel above.
+// Streaming form (default for row mode).  In the kernel above a tile is an MFMA phase followed by an HBM
+// phase, and because every tile is alike the whole chip runs the two phases in lock-step: the matrix
+// cores idle while 512 KiB of dfAvg per tile move, HBM idles during the K loops (measured: launch time
+// = MFMA time + HBM time, MFMA busy 46 %).  Here ONE persistent workgroup per CU walks its list of tiles
+// and its twelve waves are specialised:
+//   waves 0-7   (compute)  MFMA from LDS only, each a 64 x 32 part of the tile; at the end of a K loop
+//                          they leave the raw accumulators in an LDS image T of the tile
+//   waves 8, 9  (gather)   the K blocks of both operands into the two staging images, ALTERNATING: a wave
+//                          requests a whole block (32 rows x 2 x 512 B) two K blocks before it is needed
+//                          and parks it in registers meanwhile - across tile boundaries too
+//   waves 10, 11 (update)  the dual-average update of the PREVIOUS tile from T, spread over the K loop of
+//                          the current one in 8 batches of 16 rows, ALTERNATING: old dfAvg values are
+//                          requested two batches ahead; out = alpha*T + beta*old; rows and mirrored pieces
+// A wave has ONE in-order counter for its memory operations, so a wave that both requests and waits in
+// every K block can never have more than one block's worth of latency in flight; alternating waves give
+// every request two K blocks (~3.4 us) to complete, and no wave mixes the gather (on the MFMAs' critical
+// path) with the dfAvg round trips.  The row-id and weight lists sit in LDS (no dependent global load in
+// the gather).  Arithmetic, K order and the mirror rule on diagonal tiles are those of the kernel above.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST = 768;
 constexpr int SCW = 8;            // compute waves
+constexpr int SK_MAX = 2048;      // capacity of the row list held in LDS
 
 struct SyrkLds2 {
     float A[2][KB][LD];
     float B[2][KB][LD];
     float T[TB][TLD];
-};                                 // 135,168 B: one workgroup per CU
+    int32_t ids[SK_MAX];
+    float w[SK_MAX];
+};                                 // 151,552 B: one workgroup per CU
 
 struct TileRef { int i0, j0; bool diag; };
 
 // Dual-average update of the tile held in T, in row groups of 4 rows (32 per tile).
 // role 0: whole rows (s = 0..127: row s>>5 of the group, 16-byte column piece s&31); role 1: the
 // mirrored copy (s = column jl; the group's four rows are 16 contiguous bytes of the mirrored row).
-__device__ __forceinline__ f32x4 syrk_old_load(const SyrkDev &g, TileRef tr, int role, int s, int gq)
+__device__ __forceinline__ const float *syrk_piece(const SyrkDev &g, TileRef tr, int role, int s, int gq)
 {
-    if (role == 0) return *reinterpret_cast<const f32x4 *>(&g.C[(long)(tr.i0 + 4 * gq + (s >> 5)) * g.ldc + tr.j0 + 4 * (s & 31)]);
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = g.C[(long)(tr.i0 + 4 * gq + e) * g.ldc + tr.j0 + s];
-    return v;
+    // The mirrored piece takes its old values from the mirrored position - the very 16 bytes this thread
+    // overwrites, so no other wave's store can get in between - which holds the same numbers: dfAvg is
+    // exactly symmetric (this kernel keeps it so; an uploaded one is symmetrised by syrk_mirror_upper).
+    return role == 0 ? &g.C[(long)(tr.i0 + 4 * gq + (s >> 5)) * g.ldc + tr.j0 + 4 * (s & 31)]
+                     : &g.C[(long)(tr.j0 + s) * g.ldc + tr.i0 + 4 * gq];
 }
 
-template <bool SLAB>
-__device__ __forceinline__ void syrk_apply(const SyrkDev &g, const float (*T)[TLD], TileRef tr, int role, int s, int gq, f32x4 old)
+__device__ __forceinline__ f32x4 syrk_value(const SyrkDev &g, const float (*T)[TLD], int role, int s, int gq, f32x4 old)
 {
-    if (role == 0) {
-        const int row = 4 * gq + (s >> 5), c4 = 4 * (s & 31);
-        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(&T[row][c4]);
-        f32x4 o;
+    f32x4 t4;
+    if (role == 0) t4 = *reinterpret_cast<const f32x4 *>(&T[4 * gq + (s >> 5)][4 * (s & 31)]);
+    else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = fmaf(g.alpha, t4[e], g.beta * old[e]);
-        float *dst = &g.C[(long)(tr.i0 + row) * g.ldc + tr.j0 + c4];
-        if (SLAB || !tr.diag) *reinterpret_cast<f32x4 *>(dst) = o;
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (c4 + e >= row) dst[e] = o[e];                      // upper triangle of a diagonal tile
-        }
-    } else if (!SLAB) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = fmaf(g.alpha, T[4 * gq + e][s], g.beta * old[e]);
-        float *dst = &g.C[(long)(tr.j0 + s) * g.ldc + tr.i0 + 4 * gq];
-        if (!tr.diag) *reinterpret_cast<f32x4 *>(dst) = o;
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (4 * gq + e < s) dst[e] = o[e];                     // the lower triangle mirrors the upper one
-        }
+        for (int e = 0; e < 4; e++) t4[e] = T[4 * gq + e][s];
     }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = fmaf(g.alpha, t4[e], g.beta * old[e]);
+    return o;
 }
 
-// groups g0, g0+gs, .. < g1, loads and stores back to back (tails, and the flush of the last tile)
+// groups g0, g0+gs, .. < g1 with loads and stores back to back: diagonal tiles (whose lower triangle mirrors
+// the upper one element by element), short K loops, and the last tile of a workgroup
 template <bool SLAB>
 __device__ __forceinline__ void syrk_drain(const SyrkDev &g, const float (*T)[TLD], TileRef tr, int role, int s, int g0, int g1, int gs,
                                            bool use_old)
 {
+    if (SLAB && role != 0) return;
     for (int gb = g0; gb < g1; gb += 2 * gs) {
         f32x4 old[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             old[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gb + u * gs < g1 && use_old) old[u] = syrk_old_load(g, tr, role, s, gb + u * gs);
+            if (gb + u * gs < g1 && use_old) old[u] = *reinterpret_cast<const f32x4 *>(syrk_piece(g, tr, role, s, gb + u * gs));
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (gb + u * gs < g1) syrk_apply<SLAB>(g, T, tr, role, s, gb + u * gs, old[u]);
+        for (int u = 0; u < 2; u++) {
+            const int gq = gb + u * gs;
+            if (gq >= g1) continue;
+            const f32x4 o = syrk_value(g, T, role, s, gq, old[u]);
+            float *dst = const_cast<float *>(syrk_piece(g, tr, role, s, gq));
+            if (SLAB || !tr.diag) *reinterpret_cast<f32x4 *>(dst) = o;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    // role 0 keeps the upper triangle (column >= row), role 1 writes the strictly lower one
+                    const bool keep = role == 0 ? (4 * (s & 31) + e >= 4 * gq + (s >> 5)) : (4 * gq + e < s);
+                    if (keep) dst[e] = o[e];
+                }
+            }
+        }
     }
 }
 
-template <bool PAIR, bool SLAB, bool BF16>
+// tile number -> (bi, bj) of the enumeration shared with syrk_rda_kernel
+template <bool SLAB>
+__device__ __forceinline__ void syrk_tile(const SyrkDev &g, int t, int &bi, int &bj)
+{
+    if (SLAB) {
+        bi = t / g.slab_nt;
+        bj = g.slab_t0 + t % g.slab_nt;
+    } else {
+        float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
+        bi = max(0, min(g.nt - 1, (int)fb));
+        while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
+        while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
+        bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
+    }
+}
+
+// The roles are separate loops over the same tile list that meet at the same barriers: their registers
+// (accumulators; a parked K block; old dfAvg values) are then allocated as a union, not a sum.
+// Barrier protocol per tile: one at the start (T of the previous tile and the first staging image
+// complete), one per K block, one more when there is no K block at all, and one before the all-wave
+// write-out of a diagonal tile; one before the final flush.
+template <bool SLAB, bool BF16>
 __global__ __launch_bounds__(ST) void syrk_rda_stream_kernel(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds2 lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool streamer = wave >= SCW;
-    const int sid = tid - SCW * 64;                            // 0..255 in the stream waves
-    const int lr = lane & 31, lk = lane >> 5;
-    const int wm = (wave >> 2) & 1, wn = wave & 3;             // compute wave: rows wm*64.., columns wn*32..
 
     // tile list: the XCD's contiguous chunk of the tile enumeration, dealt round-robin to its workgroups
     const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
@@ -358,119 +382,168 @@ __global__ __launch_bounds__(ST) void syrk_rda_stream_kernel(SyrkDev g)
     const int xcd = blockIdx.x % nxcd, within = blockIdx.x / nxcd;
     const int q = ntiles / nxcd, r = ntiles % nxcd;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, len = q + (xcd < r ? 1 : 0);
+    const int my_tiles = len > within ? (len - within + per - 1) / per : 0;
 
     const int kact = min(*g.k_dev, g.kmax);
     const int nk = (kact + KB - 1) / KB;
     const bool use_old = (g.beta != 0.f);
-
-    const int c4 = sid & 31, rbase = (sid >> 5) & 7;           // gather mapping of the stream threads
-    int32_t id_nx[4], id2_nx[4];
-    float w_nx[4];
-    f32x4 ra[4], rb[4];
+    // the update of a tile is spread over the next tile's K loop in 8 batches of 4 row groups, starting with
+    // the SECOND K block (the first batch's old values are requested at the tile boundary and get the first
+    // block to arrive): one batch per K block when there are at least 9 of them (K > 256), else several,
+    // and whatever is left in the last block
+    const int bpi = nk > 1 ? (8 + nk - 2) / (nk - 1) : 8;
+    const int fl_pair = wave >> 1, fl_s = tid & 127;           // all-wave write-outs: 6 pairs of waves
     bool have_prev = false;
     TileRef prev{0, 0, false};
-    // share of the stream threads in a tile's update: waves 8-9 the rows, 10-11 the mirrored pieces (column-slab
-    // mode has no mirror: both halves take rows, alternate groups)
-    constexpr int SPF = SLAB ? 2 : 4;                          // row groups whose old values are prefetched per K block
-    const int d_role = SLAB ? 0 : (sid >> 7) & 1, d_s = sid & 127;
-    const int d_g0 = SLAB ? (sid >> 7) & 1 : 0, d_gs = SLAB ? 2 : 1;
-    f32x4 old_nx[SPF];
-#pragma unroll
-    for (int u = 0; u < SPF; u++) old_nx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tl = within; tl < len; tl += per) {
-        const int t = start + tl;
-        int bi, bj;
-        if (SLAB) {
-            bi = t / g.slab_nt;
-            bj = g.slab_t0 + t % g.slab_nt;
-        } else {
-            float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
-            bi = max(0, min(g.nt - 1, (int)fb));
-            while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
-            while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
-            bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
-        }
-        const int i0 = bi * TB, j0 = bj * TB;
+    for (int k = tid; k < nk * KB; k += ST) {                  // the list is zero padded to a multiple of KB
+        lds.ids[k] = g.ids[k];
+        lds.w[k] = g.w[k];
+    }
+    __syncthreads();
 
-        auto load_ids = [&](int kt) {
+    if (wave >= SCW + 2) {
+        // ================================ update waves (10, 11) ========================
+        const int uw = wave - (SCW + 2);
+        constexpr int NR = SLAB ? 1 : 2;                       // roles: rows, and mirrored pieces of the symmetric matrix
+        f32x4 old[NR][8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = kt * KB + rbase + 8 * u;
-                id_nx[u] = g.ids[k];
-                if (PAIR) id2_nx[u] = g.ids2[k];
-                w_nx[u] = g.w[k];
-            }
-        };
-        auto load_rows = [&]() {
+        for (int ro = 0; ro < NR; ro++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float *row = g.D + (long)id_nx[u] * g.ldd;
-                f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
-                f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
-                if (PAIR) {
-                    const float *row2 = g.D + (long)id2_nx[u] * g.ldd;
-                    xa -= *reinterpret_cast<const f32x4 *>(row2 + i0 + c4 * 4);
-                    xb -= *reinterpret_cast<const f32x4 *>(row2 + j0 + c4 * 4);
+            for (int v = 0; v < 8; v++) old[ro][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // item v of a batch: row group 4*batch + (it >> 7), position it & 127, it = lane + 64 v
+        auto fetch = [&](int batch) {
+#pragma unroll
+            for (int ro = 0; ro < NR; ro++)
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const int it = lane + 64 * v;
+                    old[ro][v] = *reinterpret_cast<const f32x4 *>(syrk_piece(g, prev, ro, it & 127, 4 * batch + (it >> 7)));
                 }
-                ra[u] = xa * w_nx[u];
-                rb[u] = xb;
-            }
         };
-        auto store_rows = [&](int buf) {
+        auto apply = [&](int batch) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                *reinterpret_cast<f32x4 *>(&lds.A[buf][rbase + 8 * u][c4 * 4]) = ra[u];
-                *reinterpret_cast<f32x4 *>(&lds.B[buf][rbase + 8 * u][c4 * 4]) = rb[u];
-            }
-        };
-
-        f32x16 acc[2];
+            for (int ro = 0; ro < NR; ro++)
 #pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[a][e] = 0.f;
-
-        if (streamer && nk > 0) {
-            load_ids(0);
-            load_rows();
-            if (nk > 1) load_ids(1);
-            if (have_prev && use_old) {                        // old values of the first share of the previous tile
-                const int nb = 32 / nk;
-#pragma unroll
-                for (int u = 0; u < SPF; u++) {
-                    const int gq = d_g0 + u * d_gs;
-                    if (gq < nb) old_nx[u] = syrk_old_load(g, prev, d_role, d_s, gq);
+                for (int v = 0; v < 8; v++) {
+                    const int it = lane + 64 * v;
+                    old[ro][v] = syrk_value(g, lds.T, ro, it & 127, 4 * batch + (it >> 7), old[ro][v]);
                 }
-            }
-            store_rows(0);
-        }
-        __syncthreads();                                       // staging image 0 ready; T of the previous tile complete
-        for (int kt = 0; kt < nk; kt++) {
-            const int buf = kt & 1;
-            if (streamer) {
-                if (kt + 1 < nk) load_rows();
-                if (kt + 2 < nk) load_ids(kt + 2);
+#pragma unroll
+            for (int ro = 0; ro < NR; ro++)
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const int it = lane + 64 * v;
+                    *reinterpret_cast<f32x4 *>(const_cast<float *>(syrk_piece(g, prev, ro, it & 127, 4 * batch + (it >> 7)))) = old[ro][v];
+                }
+        };
+        for (int ts = 0; ts < my_tiles; ts++) {
+            int bi, bj;
+            syrk_tile<SLAB>(g, start + within + ts * per, bi, bj);
+            int nb = uw;                                       // this wave's next batch of the previous tile
+            if (have_prev && use_old) fetch(nb);
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt++) {
                 if (have_prev) {
-                    // this K block's share of the previous tile: its old values were requested one K block ago
-                    const int ga = (kt * 32) / nk, gb = ((kt + 1) * 32) / nk;
-#pragma unroll
-                    for (int u = 0; u < SPF; u++) {
-                        const int gq = ga + d_g0 + u * d_gs;
-                        if (gq < gb) syrk_apply<SLAB>(g, lds.T, prev, d_role, d_s, gq, old_nx[u]);
-                    }
-                    if (ga + d_g0 + SPF * d_gs < gb) syrk_drain<SLAB>(g, lds.T, prev, d_role, d_s, ga + d_g0 + SPF * d_gs, gb, d_gs, use_old);
-                    if (kt + 1 < nk && use_old) {
-                        const int na = ((kt + 1) * 32) / nk, nb = ((kt + 2) * 32) / nk;
-#pragma unroll
-                        for (int u = 0; u < SPF; u++) {
-                            const int gq = na + d_g0 + u * d_gs;
-                            if (gq < nb) old_nx[u] = syrk_old_load(g, prev, d_role, d_s, gq);
-                        }
+                    const int lim = kt == nk - 1 ? 8 : min(kt * bpi, 8);
+                    while (nb < lim) {
+                        apply(nb);
+                        nb += 2;
+                        if (nb < 8 && use_old) fetch(nb);
                     }
                 }
-                if (kt + 1 < nk) store_rows(buf ^ 1);
-            } else {
+                __syncthreads();
+            }
+            if (nk == 0) {                                     // no active row: the tiles only decay (out = beta * old)
+                if (have_prev)
+                    while (nb < 8) {
+                        apply(nb);
+                        nb += 2;
+                        if (nb < 8 && use_old) fetch(nb);
+                    }
+                __syncthreads();
+            }
+            prev = TileRef{bi * TB, bj * TB, bi == bj};
+            have_prev = true;
+            if (!SLAB && bi == bj) {                           // see the compute side
+                __syncthreads();
+                syrk_drain<SLAB>(g, lds.T, prev, fl_pair & 1, fl_s, fl_pair >> 1, 32, 3, use_old);
+                have_prev = false;
+            }
+        }
+    } else if (wave >= SCW) {
+        // ================================ gather waves (8, 9) ==========================
+        // Entries e = (tile sequence number) * nk + K block, over all tiles of this workgroup; entry e is
+        // multiplied from staging image e & 1 and belongs to gather wave e & 1, which deposits it during
+        // entry e-1 and requests entry e+2 right after.
+        const int gw = wave - SCW;
+        const int c4 = lane & 31, rh = lane >> 5;              // rows rh + 2u of a K block, 16-byte piece c4
+        const int n_ent = my_tiles * nk;
+        f32x4 ga[16], gb[16];
+        auto request = [&](int e) {
+            const int ts = e / nk, blk = e - ts * nk;
+            int bi, bj;
+            syrk_tile<SLAB>(g, start + within + ts * per, bi, bj);
+            const int i0 = bi * TB, j0 = bj * TB;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float *row = g.D + (long)lds.ids[blk * KB + rh + 2 * u] * g.ldd + c4 * 4;
+                ga[u] = *reinterpret_cast<const f32x4 *>(row + i0);
+                gb[u] = *reinterpret_cast<const f32x4 *>(row + j0);
+            }
+        };
+        auto deposit = [&](int e) {
+            const int blk = e % nk, buf = e & 1;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const float wk = lds.w[blk * KB + rh + 2 * u];
+                *reinterpret_cast<f32x4 *>(&lds.A[buf][rh + 2 * u][c4 * 4]) = ga[u] * wk;
+                *reinterpret_cast<f32x4 *>(&lds.B[buf][rh + 2 * u][c4 * 4]) = gb[u];
+            }
+        };
+        if (gw < n_ent) {
+            request(gw);
+            if (gw == 0) {
+                deposit(0);
+                if (2 < n_ent) request(2);
+            }
+        }
+        for (int ts = 0; ts < my_tiles; ts++) {
+            int bi, bj;
+            syrk_tile<SLAB>(g, start + within + ts * per, bi, bj);
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt++) {
+                const int en = ts * nk + kt + 1;               // the entry multiplied after this one
+                if ((en & 1) == gw && en < n_ent) {
+                    deposit(en);
+                    if (en + 2 < n_ent) request(en + 2);
+                }
+                __syncthreads();
+            }
+            if (nk == 0) __syncthreads();
+            prev = TileRef{bi * TB, bj * TB, bi == bj};
+            have_prev = true;
+            if (!SLAB && bi == bj) {
+                __syncthreads();
+                syrk_drain<SLAB>(g, lds.T, prev, fl_pair & 1, fl_s, fl_pair >> 1, 32, 3, use_old);
+                have_prev = false;
+            }
+        }
+    } else {
+        // ================================ compute waves ===============================
+        const int lr = lane & 31, lk = lane >> 5;
+        const int wm = (wave >> 2) & 1, wn = wave & 3;         // rows wm*64.., columns wn*32.. of the tile
+        for (int ts = 0; ts < my_tiles; ts++) {
+            int bi, bj;
+            syrk_tile<SLAB>(g, start + within + ts * per, bi, bj);
+            f32x16 acc[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[a][e] = 0.f;
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt++) {
+                const int buf = (ts * nk + kt) & 1;
                 __builtin_amdgcn_s_setprio(1);
                 if (BF16) {
 #pragma unroll
@@ -487,7 +560,7 @@ __global__ __launch_bounds__(ST) void syrk_rda_stream_kernel(SyrkDev g)
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
                     }
                 } else {
-#pragma unroll 8
+#pragma unroll
                     for (int kk = 0; kk < KB / 2; kk++) {
                         const float a0 = lds.A[buf][2 * kk + lk][wm * 64 + lr];
                         const float a1 = lds.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
@@ -497,33 +570,59 @@ __global__ __launch_bounds__(ST) void syrk_rda_stream_kernel(SyrkDev g)
                     }
                 }
                 __builtin_amdgcn_s_setprio(0);
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        if (nk == 0) {                                         // no active row: the tiles only decay (out = beta * old)
-            if (have_prev && streamer) syrk_drain<SLAB>(g, lds.T, prev, d_role, d_s, d_g0, 32, d_gs, use_old);
-            __syncthreads();
-        }
-        if (!streamer) {
+            if (nk == 0) __syncthreads();
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     lds.T[wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk][wn * 32 + lr] = acc[a][e];
+            prev = TileRef{bi * TB, bj * TB, bi == bj};
+            have_prev = true;
+            if (!SLAB && bi == bj) {
+                // a diagonal tile is written out at once by all twelve waves (element-wise mirror rule): it
+                // is never the "previous tile" of the pipelined path
+                __syncthreads();
+                syrk_drain<SLAB>(g, lds.T, prev, fl_pair & 1, fl_s, fl_pair >> 1, 32, 3, use_old);
+                have_prev = false;
+            }
         }
-        have_prev = true;
-        prev = TileRef{i0, j0, bi == bj};
     }
     __syncthreads();
     if (have_prev) {
         // the last tile: all twelve waves stream it out
-        const int pair = wave >> 1, s = tid & 127;
-        if (SLAB) syrk_drain<SLAB>(g, lds.T, prev, 0, s, pair, 32, 6, use_old);
-        else syrk_drain<SLAB>(g, lds.T, prev, pair & 1, s, pair >> 1, 32, 3, use_old);
+        if (SLAB) syrk_drain<SLAB>(g, lds.T, prev, 0, fl_s, fl_pair, 32, 6, use_old);
+        else syrk_drain<SLAB>(g, lds.T, prev, fl_pair & 1, fl_s, fl_pair >> 1, 32, 3, use_old);
+    }
+}
+
+// lower triangle := upper triangle (32 x 32 blocks through LDS)
+__global__ __launch_bounds__(256) void mirror_upper_kernel(float *C, long ldc, int F)
+{
+    __shared__ float t[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi * 32 + r, j = bj * 32 + tx;
+        t[r][tx] = (i < F && j < F) ? C[(long)i * ldc + j] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bj * 32 + r, j = bi * 32 + tx;          // element (i, j) of the lower side = upper (j, i)
+        if (i < F && j < F && i > j) C[(long)i * ldc + j] = t[tx][r];
     }
 }
 
 }  // namespace
+
+void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s)
+{
+    const int nb = (F + 31) / 32;
+    hipLaunchKernelGGL(mirror_upper_kernel, dim3(nb, nb), dim3(256), 0, s, C, ldc, F);
+    DLCO_HIP(hipGetLastError());
+}
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16)
@@ -548,7 +647,10 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         g.stagger_from = n_cu;
         g.stagger_units = ntiles >= 4 * n_cu ? units : 0;      // only worth it over several rounds of tiles
     }
-    static const bool use_v1 = std::getenv("DLCO_SYRK_V1") != nullptr;
+    // The persistent, wave-specialised kernel is opt-in (DLCO_SYRK_STREAM=1): measured on MI355X it is SLOWER than
+    // the tile-per-workgroup kernel (0.39 ms against 0.30 ms at K = 303, F = 8192; 0.25 against 0.15 ms with bf16
+    // MFMAs), see DESIGN.md section 3.
+    static const bool use_v1 = std::getenv("DLCO_SYRK_STREAM") == nullptr;
     int n_wg = 256;
     {
         int dev = 0; hipDeviceProp_t prop;
@@ -561,11 +663,20 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         n_wg = std::max(8, n_cu_s / 8 * 8);
         n_wg = std::min(n_wg, (ntiles + 7) / 8 * 8);
     }
-#define DLCO_SYRK_LAUNCH(P, S, H)                                                                              \
-    do {                                                                                                       \
-        if (use_v1) hipLaunchKernelGGL((syrk_rda_kernel<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g);          \
-        else hipLaunchKernelGGL((syrk_rda_stream_kernel<P, S, H>), dim3(n_wg), dim3(ST), 0, s, g);             \
-    } while (0)
+    // pair mode (four loads per row and K block) and row lists beyond the LDS capacity stay with the tile-per-workgroup kernel
+    const bool stream = !use_v1 && !ids2 && kmax <= SK_MAX;
+    if (stream) {
+        if (bf16) {
+            if (slab) hipLaunchKernelGGL((syrk_rda_stream_kernel<true, true>), dim3(n_wg), dim3(ST), 0, s, g);
+            else hipLaunchKernelGGL((syrk_rda_stream_kernel<false, true>), dim3(n_wg), dim3(ST), 0, s, g);
+        } else {
+            if (slab) hipLaunchKernelGGL((syrk_rda_stream_kernel<true, false>), dim3(n_wg), dim3(ST), 0, s, g);
+            else hipLaunchKernelGGL((syrk_rda_stream_kernel<false, false>), dim3(n_wg), dim3(ST), 0, s, g);
+        }
+        DLCO_HIP(hipGetLastError());
+        return true;
+    }
+#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g)
     if (bf16) {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, true); else DLCO_SYRK_LAUNCH(false, true, true); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, true); else DLCO_SYRK_LAUNCH(false, false, true); }

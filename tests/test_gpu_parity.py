@@ -633,3 +633,26 @@ def test_bf16_variant_keeps_the_fpr95_band(dlco):
     assert 0.01 <= f0 <= 0.2
     assert abs(f1 - f0) <= max(1e-3, 3.0 * se) and abs(a1 - a0) <= 3e-3 and abs(r1 - r0) <= 3
     assert abs(lo1 - lo0) <= 0.05 * lo0 + 1e-4 and abs(rg1 - rg0) <= 0.05 * rg0 + 1e-4
+
+
+def test_uploaded_dual_average_is_symmetrised_from_its_upper_triangle(dlco):
+    """The fused SYRK keeps dfAvg exactly symmetric and relies on that for its mirrored stores; a dual average
+    that comes from outside (a reference checkpoint is symmetric only up to rounding) is taken from its upper
+    triangle, as the epilogue of the kernel has always done for its own output."""
+    F, N, B = 256, 1200, 48
+    D, L = synth(N, F, k=10, seed=77)
+    rng = np.random.default_rng(5)
+    df = rng.standard_normal((F, F)).astype(np.float32) * np.float32(1e-3)
+    df = (df + df.T) * np.float32(0.5)
+    noisy = df + np.tril(rng.standard_normal((F, F)).astype(np.float32) * np.float32(1e-9), -1)
+    assert not np.array_equal(noisy, noisy.T)
+    outs = []
+    for start in (df, noisy):
+        ctx = dlco.Context(F, N, B=B, seed=9)
+        ctx.set_data(D, L)
+        ctx.set_state(40, start, None)
+        ctx.step()
+        outs.append(ctx.dfavg())
+        ctx.close()
+    assert np.array_equal(outs[0], outs[0].T)
+    assert np.array_equal(outs[0], outs[1])

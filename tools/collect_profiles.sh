@@ -5,29 +5,53 @@
 #   3. the default bench line with its cpu_baseline leg
 # Outputs land in gpurun_out/profiles_new/; copy what is wanted into profiles/.
 set -e
+R=${DLCO_ROUND:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.log
-cp $OUT/stats/*/*_kernel_stats.csv $OUT/r1_bench_kernel_stats.csv
-python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/r1_bench_kernel_stats_timed.csv > $OUT/r1_bench_step_breakdown.txt
+cp $OUT/stats/*/*_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
+python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/${R}_bench_kernel_stats_timed.csv > $OUT/${R}_bench_step_breakdown.txt
 rm -rf $OUT/stats
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
-  python3 - $OUT/pmc_$c $c $OUT <<'PY'
+  DLCO_ROUND=$R python3 - $OUT/pmc_$c $c $OUT <<'PY'
 import csv, glob, sys
 d, c, out = sys.argv[1:4]
 f = glob.glob(d + "/*/*counter_collection.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if "syrk_rda" in r["Kernel_Name"] and r["Counter_Name"] == c]
 rows = rows[-20:]
-with open("%s/r1_pmc_%s_syrk.csv" % (out, c.lower()), "w") as o:
+import os
+with open("%s/%s_pmc_%s_syrk.csv" % (out, os.environ.get("DLCO_ROUND", "r2"), c.lower()), "w") as o:
     o.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n")
     for r in rows:
         o.write("%s,syrk_rda_kernel,%s,%s,%s,%s\n" % (r["Dispatch_Id"], c, r["Counter_Value"], r.get("Start_Timestamp", ""), r.get("End_Timestamp", "")))
-print(c, "mean per launch:", sum(float(r["Counter_Value"]) for r in rows) / max(len(rows), 1), "over", len(rows))
+mean = sum(float(r["Counter_Value"]) for r in rows) / max(len(rows), 1)
+print(c, "mean per launch:", mean, "over", len(rows))
+open("%s/pmc_mean_%s.txt" % (out, c), "w").write("%r %d\n" % (mean, len(rows)))
 PY
   rm -rf $OUT/pmc_$c
 done
-cd $ROOT && python3 bench.py > $OUT/r1_bench_default.json 2> $OUT/bench_default.log
-tail -c 600 $OUT/r1_bench_default.json
+DLCO_ROUND=$R python3 - $OUT <<'PY'
+import json, os, sys
+out = sys.argv[1]
+R = os.environ.get("DLCO_ROUND", "r2")
+f, nf = open(out + "/pmc_mean_FETCH_SIZE.txt").read().split()
+w, nw = open(out + "/pmc_mean_WRITE_SIZE.txt").read().split()
+f, w = float(f), float(w)
+bench = [json.loads(l) for l in open(out + "/pmc_FETCH_SIZE.json") if l.startswith("{")][-1]
+rf = bench["roofline"]
+K = rf.get("mean_active_rows_per_launch")
+F = 8192
+js = {"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --steps 20 (separate passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.sh)",
+      "kernel": rf["kernel"],
+      "note": "values are per launch, mean of the last %s launches of the SYRK in the run (mean K ~ %s rows); FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X guide, HBM section): reads are doubled" % (nf, K),
+      "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
+      "hbm_bytes_per_launch_raw": (f + w) * 1024.0, "hbm_bytes_per_launch_corrected": (2 * f + w) * 1024.0,
+      "algorithmic_bytes_per_launch": 8 * F * F + 4 * (K or 0) * F}
+json.dump(js, open("%s/%s_pmc_syrk.json" % (out, R), "w"), indent=1)
+print(json.dumps(js))
+PY
+cd $ROOT && python3 bench.py > $OUT/${R}_bench_default.json 2> $OUT/bench_default.log
+tail -c 600 $OUT/${R}_bench_default.json
