@@ -210,7 +210,7 @@ def test_comp_uprjdists_cli_feeds_pj_learn(tmp_path):
     PR = np.zeros((wcols * 8, 4096), np.float32)
     PR[:40] = make_filters(40, seed=3, scale=25.0)
     PR[5] = PR[4]                                                  # a repeat and all-zero rows (40..47)
-    w = np.array([[0.3, 0.0, 0.2, 0.1, 0.5, 0.7], [0, 0, 0, 0, 0, 1.0]], np.float32)
+    w = np.array([[0.3, 0.0, 0.2, 0.1, 0.5, 0.7], [0, 0, 0, 0, 1.0, 0], [0, 0, 0, 0, 0, 1.0]], np.float32)
     ids = rng.integers(0, 12, n)
     a, b = rng.integers(0, n, 900), rng.integers(0, n, 900)
     b[::2] = [rng.choice(np.nonzero(ids == ids[x])[0]) for x in a[::2]]
@@ -235,8 +235,11 @@ def test_comp_uprjdists_cli_feeds_pj_learn(tmp_path):
     assert L.shape == (900, 1) and np.array_equal(L.ravel(), lab) and 0 < L.sum() < 900
     # -id picks the row of "w"
     q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "1", "-out", str(tmp_path / "d1")], capture_output=True, text=True, timeout=600)
-    assert q.returncode == 0 and "Descriptor size: 0" not in q.stdout
+    assert q.returncode == 0 and "Descriptor size: 64" in q.stdout
+    # row 2 of w selects only all-zero filters, row 3 does not exist
     q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "2", "-out", str(tmp_path / "d2")], capture_output=True, text=True)
+    assert q.returncode == 2 and "no pooling region selected" in q.stderr
+    q = subprocess.run([cu, str(flt), str(img), "-prj", str(prj), "-id", "3", "-out", str(tmp_path / "d3")], capture_output=True, text=True)
     assert q.returncode == 2 and "no such row" in q.stderr
     # the next stage of the pipeline reads what this one wrote
     r = subprocess.run([pj, str(out), str(tmp_path / "model"), "-iters", "40", "-batch", "32"], capture_output=True, text=True, timeout=600)

@@ -14,6 +14,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/${R}_bench_kernel_stats_timed.csv > $OUT/${R}_bench_step_breakdown.txt
 rm -rf $OUT/stats
+# the same trace for the rank ~128 workload (BASELINE configs[2])
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $ROOT/bench.py --config c3 --no-cpu-baseline > $OUT/${R}_bench_c3.json 2> $OUT/stats_c3.log
+python3 $ROOT/tools/trace_breakdown.py $OUT/stats_c3 200 $OUT/${R}_bench_c3_kernel_stats_timed.csv > $OUT/${R}_bench_c3_step_breakdown.txt
+rm -rf $OUT/stats_c3
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
   DLCO_ROUND=$R python3 - $OUT/pmc_$c $c $OUT <<'PY'
