@@ -215,8 +215,11 @@ void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, fl
 // ---------------------------------------------------------------------------
 // One-sided Jacobi on a symmetric n x n matrix T (ld = ldt).  Output: evals[n] descending,
 // V[n][ldv] with COLUMN j = eigenvector j.  work: >= 2*n*n + 4*n floats.  n <= 1024.
+// lam_cut: a pair of columns whose eigenvalue estimates are BOTH below it is still rotated but does not
+// keep the sweeps going (the tracker's guard vectors: only their span matters, and the caller checks the
+// residuals of the pairs it keeps); the default counts every pair.
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                 hipStream_t s);
+                 hipStream_t s, float lam_cut = -3.0e38f);
 size_t jacobi_work_floats(int n);
 // CholQR building block for panels of <= 128 rows: factors the panel's Gram matrix M = L L^T
 // (only its lower triangle is read) and returns Linv = L^-1 [n][ldl] (lower triangular, upper

@@ -423,7 +423,18 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f, false);     // Yb = Qo * H, exact fp32
         gram(Yb, Qo, m_, Tm_.p);
         if (prof_) prof_->begin(PROF_JACOBI);
-        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_);
+        // Guard directions only have to span: pairs of two columns below the Ritz value of the guard at a
+        // quarter of the guard depth (known from the last pass; the leading guards above it still count,
+        // they decide guards_ok) are rotated but do not prolong the sweeps.  What this may leave unfinished
+        // shows up in the residuals below, which decide convergence.
+        float lam_cut = -3.0e38f;
+        if (guard_stop_ && have_theta_ && n_ritz == m_) {
+            int nwp = 0;
+            while (nwp < m_ && h_theta_[nwp] > mu) nwp++;
+            const int ig = nwp + std::max(2, guard_ / 4);
+            if (ig < m_) lam_cut = h_theta_[ig];
+        }
+        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_, lam_cut);
         if (prof_) prof_->end(PROF_JACOBI);
         float *Qn = pick({Qo, Yb});
         rotate(Vm_.p, cap_, m_, m_, Qo, Qn);

@@ -76,6 +76,7 @@ private:
     bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
+    bool guard_stop_ = std::getenv("DLCO_JACOBI_ALL_PAIRS") == nullptr;       // see update(): guard-guard pairs do not prolong Jacobi
     bool weighted_crit_ = std::getenv("DLCO_EIG_UNIFORM_CRIT") == nullptr;   // see update(): residuals weighted by their share in A
 
     DevBuf<float> buf_[6];           // Ritz vectors, their H-products and temporaries, each cap x F

@@ -64,10 +64,10 @@ __device__ __forceinline__ void rotation(float a, float b, float c, float &t, fl
 
 // G: column-major, column j at G + j*ldc (ldc multiple of 4, entries [n, ldc) are zero)
 // JT threads: JT / 8 pairs in flight (512: up to n = 128 in one pass per round; 1024: up to n = 256)
-template <int JT>
+template <int JT, int CH>
 __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
                             float *scratch /* >= 4n floats, global */, int *sweeps_out, float *red /* LDS, JW+4 */,
-                            float *nrm /* n floats, LDS or global */, float stop_cos)
+                            float *nrm /* n floats, LDS or global */, float stop_cos, float lam_cut)
 {
     constexpr int JW = JT / 64, NG = JT / LP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,6 +85,9 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
     float sigma = 0.f;
     for (int w = 0; w < JW; w++) sigma = fmaxf(sigma, red[w]);
     sigma = 1.01f * sigma + 1e-30f;
+    // columns whose eigenvalue estimate |g| - sigma is below lam_cut are guard directions of the caller: a pair of
+    // two such columns is rotated like any other but does not keep the sweeps going (squared norms are compared)
+    const float cut2 = lam_cut + sigma > 0.f ? (lam_cut + sigma) * (lam_cut + sigma) : 0.f;
     __syncthreads();
 
     // ---- init: G = sym(T) + sigma I, zero padding ---------------------------------------------------
@@ -129,29 +132,37 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
                 f32x4 *gq = reinterpret_cast<f32x4 *>(G + (long)q * ldc);
                 const float a = nrm[p], b = nrm[q];
                 const float ab = a * b;
-                if (nch <= 4 * LP) {
-                    // n <= 128: a lane owns at most four 16-byte chunks of each column and keeps them
-                    // in registers between the dot product and the rotation (one LDS read, one write)
-                    const bool h0 = live && sub < nch, h1 = live && sub + LP < nch, h2 = live && sub + 2 * LP < nch,
-                               h3 = live && sub + 3 * LP < nch;
-                    // the loads are unconditional (clamped chunk index) so that all eight are in flight
-                    // together; chunks a lane does not own are replaced by zeros afterwards
-                    const int k0 = min(sub, nch - 1), k1 = min(sub + LP, nch - 1), k2 = min(sub + 2 * LP, nch - 1),
-                              k3 = min(sub + 3 * LP, nch - 1);
-                    f32x4 x0 = gp[k0], y0 = gq[k0], x1 = gp[k1], y1 = gq[k1];
-                    f32x4 x2 = gp[k2], y2 = gq[k2], x3 = gp[k3], y3 = gq[k3];
-                    x0 = h0 ? x0 : z4; y0 = h0 ? y0 : z4; x1 = h1 ? x1 : z4; y1 = h1 ? y1 : z4;
-                    x2 = h2 ? x2 : z4; y2 = h2 ? y2 : z4; x3 = h3 ? x3 : z4; y3 = h3 ? y3 : z4;
-                    const float c = row8_sum((dot4(x0, y0) + dot4(x1, y1)) + (dot4(x2, y2) + dot4(x3, y3)));
+                if (nch <= CH * LP) {
+                    // a lane owns at most CH 16-byte chunks of each column (n <= 128: four, n <= 192: six) and keeps
+                    // them in registers between the dot product and the rotation (one LDS read, one write).  The
+                    // loads are unconditional (clamped chunk index) so that all of them are in flight together;
+                    // chunks a lane does not own are replaced by zeros afterwards
+                    f32x4 x[CH], y[CH];
+                    bool h[CH];
+#pragma unroll
+                    for (int e = 0; e < CH; e++) {
+                        const int ke = min(sub + e * LP, nch - 1);
+                        x[e] = gp[ke];
+                        y[e] = gq[ke];
+                        h[e] = live && sub + e * LP < nch;
+                    }
+                    float cp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < CH; e++) {
+                        x[e] = h[e] ? x[e] : z4;
+                        y[e] = h[e] ? y[e] : z4;
+                    }
+#pragma unroll
+                    for (int e = 0; e < CH; e += 2) cp += dot4(x[e], y[e]) + dot4(x[e + 1], y[e + 1]);
+                    const float c = row8_sum(cp);
                     const float off = (live && ab > 0.f) ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
-                    off_max = fmaxf(off_max, off);
+                    off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
                     if (off > tol) {
                         float t, cs, sn;
                         rotation(a, b, c, t, cs, sn);
-                        if (h0) { gp[sub] = cs * x0 - sn * y0; gq[sub] = sn * x0 + cs * y0; }
-                        if (h1) { gp[sub + LP] = cs * x1 - sn * y1; gq[sub + LP] = sn * x1 + cs * y1; }
-                        if (h2) { gp[sub + 2 * LP] = cs * x2 - sn * y2; gq[sub + 2 * LP] = sn * x2 + cs * y2; }
-                        if (h3) { gp[sub + 3 * LP] = cs * x3 - sn * y3; gq[sub + 3 * LP] = sn * x3 + cs * y3; }
+#pragma unroll
+                        for (int e = 0; e < CH; e++)
+                            if (h[e]) { gp[sub + e * LP] = cs * x[e] - sn * y[e]; gq[sub + e * LP] = sn * x[e] + cs * y[e]; }
                         if (sub == 0) { nrm[p] = a - t * c; nrm[q] = b + t * c; }
                     }
                     continue;
@@ -161,7 +172,7 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
                     for (int ch = sub; ch < nch; ch += LP) c += dot4(gp[ch], gq[ch]);
                 c = row8_sum(c);
                 const float off = (live && ab > 0.f) ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
-                off_max = fmaxf(off_max, off);
+                off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
                 if (off > tol) {
                     float t, cs, sn;
                     rotation(a, b, c, t, cs, sn);
@@ -219,20 +230,20 @@ __device__ void jacobi_body(float *G, int ldc, const float *T, long ldt, int n, 
 
 template <int JT>
 __global__ __launch_bounds__(JT) void jacobi_lds_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
-                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos)
+                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos, float lam_cut)
 {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     float *G = sh, *red = sh + (size_t)n * ldc, *nrm = red + JT / 64 + 4;
-    jacobi_body<JT>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm, stop_cos);
+    jacobi_body<JT, (JT > 512 ? 6 : 4)>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, nrm, stop_cos, lam_cut);
 }
 
 template <int JT>
 __global__ __launch_bounds__(JT) void jacobi_gmem_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
-                                                         long ldv, float *work, int *sweeps_out, float stop_cos)
+                                                         long ldv, float *work, int *sweeps_out, float stop_cos, float lam_cut)
 {
     __shared__ float red[JT / 64 + 4];
     float *G = work, *scratch = work + (size_t)n * ldc;
-    jacobi_body<JT>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos);
+    jacobi_body<JT, 4>(G, ldc, T, ldt, n, evals, Vout, ldv, scratch, sweeps_out, red, scratch + 3 * (size_t)n, stop_cos, lam_cut);
 }
 
 // ---- n <= 128: one column pair per 16 lanes ------------------------------------------------------
@@ -268,7 +279,7 @@ inline size_t j16_lds_bytes(int n)
 
 template <int E>
 __global__ __launch_bounds__(1024) void jacobi16_kernel(const float *T, long ldt, int n, int ldc, float *evals, float *Vout,
-                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos)
+                                                        long ldv, float *scratch, int *sweeps_out, float stop_cos, float lam_cut)
 {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     float *G = sh;                                   // [n][ldc], column j at G + j*ldc
@@ -304,6 +315,9 @@ __global__ __launch_bounds__(1024) void jacobi16_kernel(const float *T, long ldt
     float sigma = 0.f;
     for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
     sigma = 1.01f * sigma + 1e-30f;
+    // columns whose eigenvalue estimate |g| - sigma is below lam_cut are guard directions of the caller: a pair of
+    // two such columns is rotated like any other but does not keep the sweeps going (squared norms are compared)
+    const float cut2 = lam_cut + sigma > 0.f ? (lam_cut + sigma) * (lam_cut + sigma) : 0.f;
 
     // ---- init: G = sym(T) + sigma I, zero padding ---------------------------------------------------
     for (int e = tid; e < n * ldc; e += nthr) {
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(1024) void jacobi16_kernel(const float *T, long ldt
             c = row16_sum(c);
             const float ab = a * b;
             const float off = (live && ab > 0.f) ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
-            off_max = fmaxf(off_max, off);
+            off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
             if (off > tol) {
                 float t, cs, sn;
                 rotation(a, b, c, t, cs, sn);
@@ -412,7 +426,7 @@ inline size_t jseat_lds_bytes(int n) { const int ne = n + (n & 1); return ((size
 
 template <int E>
 __global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
-                                                           float *scratch, int *sweeps_out, float stop_cos)
+                                                           float *scratch, int *sweeps_out, float stop_cos, float lam_cut)
 {
     constexpr int LDC = 32 * E + 16;
     extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -434,6 +448,9 @@ __global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long 
     float sigma = 0.f;
     for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
     sigma = 1.01f * sigma + 1e-30f;
+    // columns whose eigenvalue estimate |g| - sigma is below lam_cut are guard directions of the caller: a pair of
+    // two such columns is rotated like any other but does not keep the sweeps going (squared norms are compared)
+    const float cut2 = lam_cut + sigma > 0.f ? (lam_cut + sigma) * (lam_cut + sigma) : 0.f;
     // ---- column j of G = sym(T) + sigma I starts in slot j; slot n (odd n) is a zero column (the bye) ---
     for (int e = tid; e < ne * LDC; e += nthr) {
         const int j = e / LDC, i = e % LDC;
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long 
                 }
                 const float ab = a * b;
                 const float off = ab > 0.f ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
-                off_max = fmaxf(off_max, off);
+                off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
                 float cs = 1.f, sn = 0.f, tc = 0.f;
                 if (off > tol) {
                     float t;
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long 
 
 template <int E>
 void launch_jacobi_seat(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                        float stop_cos, hipStream_t s)
+                        float stop_cos, float lam_cut, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
@@ -548,7 +565,7 @@ void launch_jacobi_seat(const float *T, long ldt, int n, float *evals, float *V,
         attr = true;
     }
     hipLaunchKernelGGL(jacobi_seat_kernel<E>, dim3(1), dim3(j16_threads(n)), jseat_lds_bytes(n), s, T, ldt, n, evals, V, ldv, work,
-                       sweeps_out, stop_cos);
+                       sweeps_out, stop_cos, lam_cut);
 }
 
 inline int col_stride(int n) { return (n + 3) & ~3; }
@@ -558,7 +575,7 @@ inline int col_stride(int n) { return (n + 3) & ~3; }
 size_t jacobi_work_floats(int n) { return (size_t)n * col_stride(n) + 4 * (size_t)n + 64; }
 
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                 hipStream_t s)
+                 hipStream_t s, float lam_cut)
 {
     DLCO_CHECK(n >= 1 && n <= 4096, -2, "jacobi_eigh: n out of range");
     const int ldc = col_stride(n);
@@ -568,10 +585,10 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
     static const bool use_v2 = std::getenv("DLCO_JACOBI_V2") != nullptr;
     if (n <= J16_MAX_N && !use_v1 && !use_v2) {
         const int e = j16_chunks(n);
-        if (e == 1) launch_jacobi_seat<1>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
-        else if (e == 2) launch_jacobi_seat<2>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
-        else if (e == 3) launch_jacobi_seat<3>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
-        else launch_jacobi_seat<4>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, s);
+        if (e == 1) launch_jacobi_seat<1>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else if (e == 2) launch_jacobi_seat<2>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else if (e == 3) launch_jacobi_seat<3>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else launch_jacobi_seat<4>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
     } else if (n <= J16_MAX_N && !use_v1) {
         static bool attr16 = false;
         if (!attr16) {
@@ -584,10 +601,10 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         const int e = j16_chunks(n), ldc16 = j16_ldc(n);
         const dim3 grid(1), block(j16_threads(n));
         const size_t lds16 = j16_lds_bytes(n);
-        if (e == 1) hipLaunchKernelGGL(jacobi16_kernel<1>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
-        else if (e == 2) hipLaunchKernelGGL(jacobi16_kernel<2>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
-        else if (e == 3) hipLaunchKernelGGL(jacobi16_kernel<3>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
-        else hipLaunchKernelGGL(jacobi16_kernel<4>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos);
+        if (e == 1) hipLaunchKernelGGL(jacobi16_kernel<1>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
+        else if (e == 2) hipLaunchKernelGGL(jacobi16_kernel<2>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
+        else if (e == 3) hipLaunchKernelGGL(jacobi16_kernel<3>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
+        else hipLaunchKernelGGL(jacobi16_kernel<4>, grid, block, lds16, s, T, ldt, n, ldc16, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
     } else if (n <= JACOBI_LDS_MAX_N) {
         // 8 lanes per pair: 512 threads cover 64 pairs per pass, 1024 threads 128 (n > 128: one pass per round)
         const bool wide = n > 128;
@@ -600,12 +617,12 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             attr_set = true;
         }
-        if (wide) hipLaunchKernelGGL(jacobi_lds_kernel<1024>, dim3(1), dim3(1024), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
-        else hipLaunchKernelGGL(jacobi_lds_kernel<512>, dim3(1), dim3(512), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        if (wide) hipLaunchKernelGGL(jacobi_lds_kernel<1024>, dim3(1), dim3(1024), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
+        else hipLaunchKernelGGL(jacobi_lds_kernel<512>, dim3(1), dim3(512), lds, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
     } else if (n <= 256) {
-        hipLaunchKernelGGL(jacobi_gmem_kernel<1024>, dim3(1), dim3(1024), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        hipLaunchKernelGGL(jacobi_gmem_kernel<1024>, dim3(1), dim3(1024), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
     } else {
-        hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos);
+        hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, ldc, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
     }
     DLCO_HIP(hipGetLastError());
 }
