@@ -330,6 +330,11 @@ int  dlco_desc_compute_device(dlco_desc_ctx *ctx, const uint8_t *patches_host, i
  * (patchID1, 3DpointID1, patchID2, 3DpointID2): the two datasets comp-uprjdists writes */
 int  dlco_desc_pair_dists(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
                           int64_t n_pairs, float *dist_host, uint8_t *label_host);
+/* comp-fulldists (src/comp-fulldists.cpp:285-369), the producer of pr-learn's input: with ALL pooling-region
+ * filters set (8 rows per region), Distance [n_pairs, rows/8] = per region, the sum over its 8 rows and 8 bins of
+ * (Desc2 - Desc1)^2 (cuda::subtract / pow / reduce there), and Label (may be NULL) */
+int  dlco_desc_full_dists(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                          int64_t n_pairs, float *dist_host, uint8_t *label_host);
 double dlco_desc_last_kernel_ms(const dlco_desc_ctx *ctx);               /* HIP-event time of the last compute call */
 
 #ifdef __cplusplus

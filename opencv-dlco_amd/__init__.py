@@ -134,6 +134,7 @@ def load():
     L.dlco_desc_compute.argtypes = [vp, u8p, i64, f32p]
     L.dlco_desc_compute_device.argtypes = [vp, u8p, i64, vp, i64]
     L.dlco_desc_pair_dists.argtypes = [vp, u8p, i64, i32p, i64, f32p, u8p]
+    L.dlco_desc_full_dists.argtypes = [vp, u8p, i64, i32p, i64, f32p, u8p]
     L.dlco_desc_last_kernel_ms.argtypes = [vp]
     L.dlco_desc_last_kernel_ms.restype = C.c_double
     L.dlco_pr_last_error.restype = C.c_char_p
@@ -584,6 +585,15 @@ class DescContext:
         dist = np.empty((q.shape[0], self.size), np.float32)
         lab = np.empty(q.shape[0], np.uint8)
         self._ck(self.L.dlco_desc_pair_dists(self.h, _p(p, u8p), p.shape[0], _p(q, i32p), q.shape[0], _p(dist, f32p), _p(lab, u8p)))
+        return dist, lab
+
+    def full_dists(self, patches, pairs):
+        """comp-fulldists: per-region squared descriptor distances [n_pairs, rows/8] and labels (pr-learn's input)."""
+        p, q = np.ascontiguousarray(patches, np.uint8), _i32(pairs)
+        assert p.ndim == 3 and p.shape[1:] == (64, 64) and q.ndim == 2 and q.shape[1] == 4
+        dist = np.empty((q.shape[0], max(1, self.size // 64)), np.float32)
+        lab = np.empty(q.shape[0], np.uint8)
+        self._ck(self.L.dlco_desc_full_dists(self.h, _p(p, u8p), p.shape[0], _p(q, i32p), q.shape[0], _p(dist, f32p), _p(lab, u8p)))
         return dist, lab
 
     def last_kernel_ms(self):

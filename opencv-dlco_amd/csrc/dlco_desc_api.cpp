@@ -19,6 +19,7 @@ void desc_transform(const uint8_t *patches, int n_patches, const float *cf, int 
                     float *PT, hipStream_t s);
 void desc_pool(const float *PT, int n_patches, const float *Fl, int nsel, int nsel_pad, float *desc, long desc_ld, hipStream_t s);
 void desc_pair_diff(const float *desc, long ld, int F, const int32_t *pairs, long n_pairs, float *dist, uint8_t *label, hipStream_t s);
+void desc_full_dist(const float *desc, long ld, int n_groups, int n_pairs, float *dist, hipStream_t s);
 }
 
 namespace {
@@ -293,6 +294,48 @@ int dlco_desc_pair_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t 
             if (label_host) DLCO_HIP(hipMemcpyAsync(label_host + p0, lab.p, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
             sync(c);
         }
+    });
+}
+
+// The output of comp-fulldists (src/comp-fulldists.cpp:285-369), the input of pr-learn: with ALL pooling-region
+// filters set (rows = 8 * n_regions, one row per ring replica), Distance [n_pairs, n_regions] =
+// sum over a region's 8 rows and 8 bins of (Desc2 - Desc1)^2, and Label.  A patch's full descriptor is
+// rows * 8 floats (1.3 MB at 5120 regions), so the work goes by chunks of pairs: both patches of a chunk are
+// transformed and pooled, reduced per pair, and dropped.
+int dlco_desc_full_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host, int64_t n_pairs,
+                         float *dist_host, uint8_t *label_host)
+{
+    if (!c || !patches_host || !pairs_host || !dist_host || n_patches < 1 || n_pairs < 1) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_CHECK(c->nsel > 0 && c->nsel % 8 == 0, DLCO_ERR_INVALID, "dlco_desc_full_dists: the filter bank must hold 8 rows per pooling region");
+        const int F = c->nsel * kBins, groups = c->nsel / 8;
+        for (int64_t i = 0; i < n_pairs; i++) {
+            const int32_t *q = pairs_host + i * 4;
+            DLCO_CHECK(q[0] >= 0 && q[0] < n_patches && q[2] >= 0 && q[2] < n_patches, DLCO_ERR_INVALID, "dlco_desc: patch id out of range");
+            if (label_host) label_host[i] = (q[1] == q[3]) ? 1 : 0;               // :268-272 of both tools
+        }
+        DLCO_HIP(hipSetDevice(c->device));
+        // pairs per chunk: 2 * chunk descriptors of F floats within ~2 GB, and within one transform chunk
+        const int64_t pchunk = std::max<int64_t>(1, std::min<int64_t>(kChunk / 2, ((int64_t)1 << 29) / ((int64_t)2 * F)));
+        DevBuf<float> desc, dist;
+        desc.alloc((size_t)2 * pchunk * F);
+        dist.alloc((size_t)pchunk * groups);
+        std::vector<uint8_t> stage((size_t)2 * pchunk * kPix);
+        double ms_total = 0.0;
+        for (int64_t p0 = 0; p0 < n_pairs; p0 += pchunk) {
+            const int64_t cnt = std::min(pchunk, n_pairs - p0);
+            for (int64_t i = 0; i < cnt; i++) {
+                const int32_t *q = pairs_host + (p0 + i) * 4;
+                std::memcpy(stage.data() + (size_t)i * kPix, patches_host + (size_t)q[0] * kPix, kPix);
+                std::memcpy(stage.data() + (size_t)(cnt + i) * kPix, patches_host + (size_t)q[2] * kPix, kPix);
+            }
+            compute(c, stage.data(), 2 * cnt, desc.p, true, F);
+            ms_total += c->last_ms;
+            desc_full_dist(desc.p, F, groups, (int)cnt, dist.p, c->stream);
+            DLCO_HIP(hipMemcpyAsync(dist_host + p0 * groups, dist.p, (size_t)cnt * groups * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            sync(c);
+        }
+        c->last_ms = ms_total;
     });
 }
 

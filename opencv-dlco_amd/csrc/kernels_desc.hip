@@ -277,6 +277,25 @@ __global__ __launch_bounds__(256) void desc_pair_diff_kernel(const float *desc, 
     if (threadIdx.x == 0 && label) label[pr] = (q[1] == q[3]) ? 1 : 0;                    // :268-272
 }
 
+// comp-fulldists (src/comp-fulldists.cpp:318-343): per pair and pooling region g (8 ring rows x 8 bins = 64
+// consecutive descriptor entries), dist[g] = sum (Desc2 - Desc1)^2.  16 lanes per region: a 16-byte piece each,
+// squared and summed in the reference's grouping (the 8 bins of a row first, then the 8 rows).
+__global__ __launch_bounds__(256) void desc_full_dist_kernel(const float *desc, long ld, int n_groups, int n_pairs, float *dist)
+{
+    const long pr = blockIdx.y;
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    if (pr >= n_pairs || g >= n_groups) return;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(desc + pr * ld + (long)g * 64 + 4 * l);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(desc + (pr + n_pairs) * ld + (long)g * 64 + 4 * l);
+    const f32x4 d = b - a;
+    float s = ((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3];      // half a row: 4 of its 8 bins
+    s += __shfl_xor(s, 1, 64);                                                 // the row
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);                                                 // the 8 rows
+    if (l == 0) dist[pr * n_groups + g] = s;
+}
+
 __global__ __launch_bounds__(256) void desc_permute_filters_kernel(const float *src, int nsel, float *dst)
 {
     // dst[f][y*64+x] = src[f][x*64+y]
@@ -316,6 +335,14 @@ void desc_pool(const float *PT, int n_patches, const float *Fl, int nsel, int ns
     const int groups = (tiles_n + 7) / 8;
     hipLaunchKernelGGL(desc_pool_kernel, dim3(groups * tiles_f * 8), dim3(GTH), 0, s, PT, Fl, n_rows, nsel_pad * 8, nsel, desc, desc_ld,
                        tiles_f);
+    DLCO_HIP(hipGetLastError());
+}
+
+// desc: [2 * n_pairs][ld], rows [0, n_pairs) the first patch of every pair, rows [n_pairs, 2 n_pairs) the second
+void desc_full_dist(const float *desc, long ld, int n_groups, int n_pairs, float *dist, hipStream_t s)
+{
+    if (n_pairs <= 0 || n_groups <= 0) return;
+    hipLaunchKernelGGL(desc_full_dist_kernel, dim3((n_groups + 15) / 16, n_pairs), dim3(256), 0, s, desc, ld, n_groups, n_pairs, dist);
     DLCO_HIP(hipGetLastError());
 }
 

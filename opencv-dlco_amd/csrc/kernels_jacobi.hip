@@ -554,6 +554,156 @@ __global__ __launch_bounds__(1024) void jacobi_seat_kernel(const float *T, long 
     }
 }
 
+// ---- the same seat scheme with 8 lanes per pair (16-byte chunks) -------------------------------------------
+// PING = true : two LDS images, one barrier per round (n <= 128), half the waves of the 16-lane form;
+// PING = false: ONE image, read -> barrier -> write -> barrier, for 128 < n <= 190 where two images of the
+//               matrix do not fit 160 KB (the rank ~128 workload: blocks of 148 - 160 rows).
+inline int jseat8_threads(int n) { const int half = (n + 1) / 2; return ((half * 8 + 63) / 64) * 64; }
+inline size_t jseat8_lds_bytes(int n, bool ping) { const int ne = n + (n & 1); return ((size_t)(ping ? 2 : 1) * ne * jseat_ldc(n) + 32) * sizeof(float); }
+
+template <int E, bool PING>
+__global__ __launch_bounds__(1024) void jacobi_seat8_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
+                                                            float *scratch, int *sweeps_out, float stop_cos, float lam_cut)
+{
+    constexpr int LDC = 32 * E + 16;
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int ne = n + (n & 1), h = ne / 2;
+    float *buf0 = sh, *buf1 = PING ? sh + (size_t)ne * LDC : sh, *red = sh + (size_t)(PING ? 2 : 1) * ne * LDC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;
+
+    float rmax = 0.f;                                          // Gershgorin shift, as in jacobi_seat_kernel
+    for (int i = wave; i < n; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += fabsf(T[(long)i * ldt + j]);
+        s = wsum(s);
+        rmax = fmaxf(rmax, s);
+    }
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    float sigma = 0.f;
+    for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
+    sigma = 1.01f * sigma + 1e-30f;
+    const float cut2 = lam_cut + sigma > 0.f ? (lam_cut + sigma) * (lam_cut + sigma) : 0.f;
+    for (int e = tid; e < ne * LDC; e += nthr) {
+        const int j = e / LDC, i = e % LDC;
+        float v = 0.f;
+        if (i < n && j < n) v = 0.5f * (T[(long)i * ldt + j] + T[(long)j * ldt + i]) + (i == j ? sigma : 0.f);
+        buf0[e] = v;
+    }
+    __syncthreads();
+
+    const float tol = 3e-6f;
+    const int grp = tid >> 3, sub = tid & 7;
+    const bool seated = grp < h;
+    int dtop = 2 * grp, dbot = 2 * grp + 1;
+    if (h > 1) {
+        dtop = grp == 0 ? 0 : (grp < h - 1 ? 2 * (grp + 1) : 2 * (h - 1) + 1);
+        dbot = grp == 0 ? 2 : 2 * (grp - 1) + 1;
+    }
+    const int src_off = (seated ? 2 * grp : 0) * LDC + 4 * sub;
+    const int dtop_off = (seated ? dtop : 0) * LDC + 4 * sub, dbot_off = (seated ? dbot : 0) * LDC + 4 * sub;
+    int it = 0, sweep = 0;
+    for (; sweep < 40; sweep++) {
+        float off_max = 0.f;
+        for (int r = 0; r < ne - 1; r++, it++) {
+            const float *cur = (PING && (it & 1)) ? buf1 : buf0;
+            float *nxt = (PING && !(it & 1)) ? buf1 : buf0;
+            f32x4 x[E], y[E];
+            float cs = 1.f, sn = 0.f, na = 0.f, nb = 0.f;
+            if (seated) {
+                const float *st = cur + src_off, *sb = st + LDC;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    x[e] = *reinterpret_cast<const f32x4 *>(st + 32 * e);
+                    y[e] = *reinterpret_cast<const f32x4 *>(sb + 32 * e);
+                }
+                float a = st[32 * E - 4 * sub], b = sb[32 * E - 4 * sub];      // the norms ride behind the padding
+                float c = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; e++) c += dot4(x[e], y[e]);
+                c = row8_sum(c);
+                if (r == 0) {                                        // exact squared norms at the start of a sweep
+                    float sa = 0.f, sb2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; e++) { sa += dot4(x[e], x[e]); sb2 += dot4(y[e], y[e]); }
+                    a = row8_sum(sa);
+                    b = row8_sum(sb2);
+                }
+                const float ab = a * b;
+                const float off = ab > 0.f ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
+                off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
+                float tc = 0.f;
+                if (off > tol) {
+                    float t;
+                    rotation(a, b, c, t, cs, sn);
+                    tc = t * c;
+                }
+                na = a - tc; nb = b + tc;
+            }
+            if (!PING) __syncthreads();                              // every seat has read the image before any writes it
+            if (seated) {
+                float *wt = nxt + dtop_off, *wb = nxt + dbot_off;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    *reinterpret_cast<f32x4 *>(wt + 32 * e) = cs * x[e] - sn * y[e];
+                    *reinterpret_cast<f32x4 *>(wb + 32 * e) = sn * x[e] + cs * y[e];
+                }
+                if (sub == 0) { wt[32 * E] = na; wb[32 * E] = nb; }
+            }
+            __syncthreads();
+        }
+        off_max = wmax(off_max);
+        if (lane == 0) red[wave] = off_max;
+        __syncthreads();
+        float m = 0.f;
+        for (int w = 0; w < nw; w++) m = fmaxf(m, red[w]);
+        __syncthreads();
+        if (m <= stop_cos) { sweep++; break; }
+    }
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+
+    const float *G = (PING && (it & 1)) ? buf1 : buf0;
+    float *lam = scratch, *inv = scratch + ne;
+    int *rank = reinterpret_cast<int *>(scratch + 2 * ne);
+    for (int j = wave; j < ne; j += nw) {
+        float d = 0.f;
+        for (int i = lane; i < n; i += 64) { const float v = G[(long)j * LDC + i]; d += v * v; }
+        d = wsum(d);
+        if (lane == 0) { const float nr = sqrtf(d); lam[j] = nr > 0.f ? nr - sigma : -3.0e38f; inv[j] = nr > 0.f ? 1.f / nr : 0.f; }
+    }
+    __syncthreads();
+    for (int j = tid; j < ne; j += nthr) {
+        const float me = lam[j];
+        int rk = 0;
+        for (int k = 0; k < ne; k++) {
+            const float o = lam[k];
+            rk += (o > me || (o == me && k < j)) ? 1 : 0;
+        }
+        rank[j] = rk;
+        if (rk < n) evals[rk] = me;
+    }
+    __syncthreads();
+    for (int e = tid; e < ne * n; e += nthr) {
+        const int j = e / n, i = e % n;
+        if (rank[j] < n) Vout[(long)i * ldv + rank[j]] = G[(long)j * LDC + i] * inv[j];
+    }
+}
+
+template <int E, bool PING>
+void launch_jacobi_seat8(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
+                         float stop_cos, float lam_cut, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_seat8_kernel<E, PING>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((jacobi_seat8_kernel<E, PING>), dim3(1), dim3(jseat8_threads(n)), jseat8_lds_bytes(n, PING), s, T, ldt, n, evals, V, ldv,
+                       work, sweeps_out, stop_cos, lam_cut);
+}
+
 template <int E>
 void launch_jacobi_seat(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
                         float stop_cos, float lam_cut, hipStream_t s)
@@ -583,7 +733,18 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
     static const float stop_cos = std::getenv("DLCO_JACOBI_STOP") ? (float)std::atof(std::getenv("DLCO_JACOBI_STOP")) : 1e-3f;
     static const bool use_v1 = std::getenv("DLCO_JACOBI_V1") != nullptr;
     static const bool use_v2 = std::getenv("DLCO_JACOBI_V2") != nullptr;
-    if (n <= J16_MAX_N && !use_v1 && !use_v2) {
+    static const bool use_lp8 = std::getenv("DLCO_JACOBI_LP8") != nullptr;         // 8-lane seats for n <= 128 as well
+    static const bool no_wide_seat = std::getenv("DLCO_JACOBI_NO_WIDE_SEAT") != nullptr;
+    if (n > J16_MAX_N && n <= 190 && !use_v1 && !no_wide_seat && jseat8_lds_bytes(n, false) <= 160 * 1024 - 1024) {
+        if (j16_chunks(n) == 5) launch_jacobi_seat8<5, false>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else launch_jacobi_seat8<6, false>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+    } else if (n <= J16_MAX_N && use_lp8 && !use_v1 && !use_v2) {
+        const int e = j16_chunks(n);
+        if (e == 1) launch_jacobi_seat8<1, true>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else if (e == 2) launch_jacobi_seat8<2, true>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else if (e == 3) launch_jacobi_seat8<3, true>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else launch_jacobi_seat8<4, true>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+    } else if (n <= J16_MAX_N && !use_v1 && !use_v2) {
         const int e = j16_chunks(n);
         if (e == 1) launch_jacobi_seat<1>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
         else if (e == 2) launch_jacobi_seat<2>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);

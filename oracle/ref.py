@@ -470,3 +470,17 @@ def select_pr_filters(pr_filters, w):
                 continue
             break
     return s
+
+
+def full_dists(patch1, patch2, pr_filters):
+    """One row of comp-fulldists' "Distance" (src/comp-fulldists.cpp:318-343): PRFilters [8*n_regions, 4096],
+    dist[g] = sum over the region's 8 rows and 8 bins of (Desc2 - Desc1)^2, row sums first (cuda::reduce twice).
+    The reference forms Desc with cuda::gemm (fp32, order unspecified); here with the double accumulation of
+    patch_descriptor — the comparison tolerance covers the difference."""
+    f = np.ascontiguousarray(pr_filters, np.float32)
+    assert f.shape[0] % 8 == 0
+    d1 = patch_descriptor(patch1, f).reshape(-1, 8)
+    d2 = patch_descriptor(patch2, f).reshape(-1, 8)
+    l2 = (d2 - d1) ** np.float32(2)
+    rows = l2.sum(axis=1, dtype=np.float32)
+    return rows.reshape(-1, 8).sum(axis=1, dtype=np.float32)

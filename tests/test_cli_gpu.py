@@ -245,3 +245,69 @@ def test_comp_uprjdists_cli_feeds_pj_learn(tmp_path):
     r = subprocess.run([pj, str(out), str(tmp_path / "model"), "-iters", "40", "-batch", "32"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     assert "Load Distances: 900 x 248" in r.stdout
+
+
+def test_full_pipeline_of_the_reference_tools(tmp_path):
+    """BASELINE configs[4] as plumbing: comp-fulldists -> pr-learn -> comp-uprjdists -> pj-learn -> eval-fpr95,
+    every stage reading the files the previous one wrote, with the dataset names of the reference's
+    workspace scripts; the learned projection is scored on a SECOND patch set (cross-set evaluation)."""
+    from test_descriptors import make_filters, make_patches
+    subprocess.check_call(["make", "-s", "-C", CLI])
+    tool = lambda t: os.path.join(CLI, t)
+    regions = 16
+
+    def patch_set(seed, n=160, npairs=1200):
+        rng = np.random.default_rng(seed)
+        base = make_patches(40, seed=seed)                              # 40 "3D points", 4 noisy views each
+        patches = np.concatenate([np.clip(base.astype(np.float32) + rng.normal(0, 4 + 3 * v, base.shape), 0, 255).astype(np.uint8)
+                                  for v in range(n // 40)])
+        ids = np.tile(np.arange(40), n // 40)
+        a, b = rng.integers(0, n, npairs), rng.integers(0, n, npairs)
+        b[::2] = [rng.choice(np.nonzero(ids == ids[x])[0]) for x in a[::2]]
+        return patches, np.stack([a, ids[a], b, ids[b]], 1).astype(np.int32)
+
+    PR = make_filters(8 * regions, seed=17, scale=20.0)
+    PRParams = np.zeros((8 * 8 * regions, 3), np.float32)
+    PRParams[:, 0] = 1 + (np.arange(8 * 8 * regions) % 3)
+    flt = tmp_path / "filters"
+    flt.mkdir()
+    np.save(flt / "PRFilters.npy", PR.reshape(-1, 64, 64))
+    np.save(flt / "PRParams.npy", PRParams)
+    np.save(flt / "RingParams.npy", np.zeros((5, 3), np.float32))
+    sets = {}
+    for name, seed in (("train", 1), ("test", 2)):
+        d = tmp_path / name
+        d.mkdir()
+        patches, pairs = patch_set(seed)
+        np.save(d / "Patches.npy", patches)
+        np.save(d / "Indices.npy", pairs)
+        sets[name] = d
+    run = lambda args: subprocess.run(args, capture_output=True, text=True, timeout=900)
+    # 1. pooling-region distances of the training set
+    r = run([tool("comp-fulldists"), str(flt), str(sets["train"]), str(tmp_path / "fulldists")])
+    assert r.returncode == 0 and "Bins: #8 Sigma: 1.4 bNorm: 1" in r.stdout, r.stderr
+    full = np.load(tmp_path / "fulldists" / "Distance.npy")
+    assert full.shape == (1200, regions) and (full >= 0).all()
+    # 2. pooling-region selection
+    r = run([tool("pr-learn"), str(flt), str(tmp_path / "fulldists"), str(tmp_path / "prs"), "-mu", "0.001", "-gamma", "0.5", "-iters", "6000",
+             "-logstep", "2000", "-maxdim", "100000"])
+    assert r.returncode == 0 and "[saved]" in r.stdout, r.stdout + r.stderr
+    w = np.load(tmp_path / "prs" / "w.npy")
+    assert w.shape[1] == regions and (w[-1] > 0).any()
+    # 3. descriptors of the selected regions, both sets
+    for name in sets:
+        r = run([tool("comp-uprjdists"), str(flt), str(sets[name]), "-prj", str(tmp_path / "prs"), "-id", str(len(w) - 1), "-out", str(tmp_path / (name + "-unproj"))])
+        assert r.returncode == 0, r.stderr
+    D = np.load(tmp_path / "train-unproj" / "Distance.npy")
+    assert D.shape[0] == 1200 and D.shape[1] % 8 == 0
+    # 4. the projection
+    r = run([tool("pj-learn"), str(tmp_path / "train-unproj"), str(tmp_path / "model"), "-iters", "150", "-batch", "64", "-logstep", "50", "-mu", "0.002"])
+    assert r.returncode == 0 and "[saved]" in r.stdout, r.stdout + r.stderr
+    # 5. cross-set evaluation
+    r = run([tool("eval-fpr95"), str(tmp_path / "model"), str(tmp_path / "test-unproj")])
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"FPR95: (\d+\.\d+)", r.stdout)
+    assert m and 0.0 <= float(m.group(1)) <= 100.0
+    own = run([tool("eval-fpr95"), str(tmp_path / "model"), str(tmp_path / "train-unproj")])
+    assert own.returncode == 0
+    print("pipeline: FPR95 on the training set", re.search(r"FPR95: (\d+\.\d+)", own.stdout).group(1), "cross-set", m.group(1))

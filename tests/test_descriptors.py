@@ -251,3 +251,38 @@ def test_descriptor_table_feeds_pair_mode_in_hbm():
         outs.append(c.W().copy())
         c.close()
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+
+
+def test_oracle_full_dists_grouping():
+    """comp-fulldists' reduction (src/comp-fulldists.cpp:337-343): per region, 8 ring rows x 8 bins."""
+    patches = make_patches(2, seed=44)
+    PR = make_filters(24, seed=6, scale=20.0)                          # 3 regions x 8 rows
+    d = ref.full_dists(patches[0], patches[1], PR)
+    d1 = ref.patch_descriptor(patches[0], PR).astype(np.float64)
+    d2 = ref.patch_descriptor(patches[1], PR).astype(np.float64)
+    want = ((d2 - d1) ** 2).reshape(3, 64).sum(1)
+    assert d.shape == (3,) and np.allclose(d, want, rtol=1e-6)
+    assert np.array_equal(ref.full_dists(patches[0], patches[0], PR), np.zeros(3, np.float32))
+
+
+@pytest.mark.gpu
+def test_full_dists_match_oracle():
+    """dlco_desc_full_dists = the Distance / Label datasets of comp-fulldists (pr-learn's input)."""
+    n, regions = 90, 12
+    patches = make_patches(n, seed=51)
+    PR = make_filters(8 * regions, seed=9, scale=20.0)
+    rng = np.random.default_rng(4)
+    pairs = np.stack([rng.integers(0, n, 70), rng.integers(0, 9, 70), rng.integers(0, n, 70), rng.integers(0, 9, 70)], 1).astype(np.int32)
+    pairs[5, 2] = pairs[5, 0]                                          # a patch paired with itself: distance 0
+    ctx = dlco.DescContext()
+    ctx.set_filters(PR)
+    dist, lab = ctx.full_dists(patches, pairs)
+    want = np.stack([ref.full_dists(patches[a], patches[b], PR) for a, _, b, _ in pairs])
+    assert dist.shape == (70, regions) and (dist[5] == 0).all()
+    # the reference forms this with cuda::gemm / cuda::reduce (fp32, order unspecified): 1e-5 of the row scale
+    assert np.abs(dist - want).max() <= 1e-5 * want.max()
+    assert np.array_equal(lab, (pairs[:, 1] == pairs[:, 3]).astype(np.uint8))
+    with pytest.raises(dlco.DlcoError):
+        bad = dlco.DescContext()
+        bad.set_filters(PR[:12])                                       # not 8 rows per region
+        bad.full_dists(patches, pairs)
