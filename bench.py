@@ -57,7 +57,7 @@ WORKLOADS = {
     "c3": dict(name="configs[2] NotreDame-shaped, rank ~128", F=8192, N=500000, batch=200, mu=0.001, gamma=0.5,
                latent=192, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
                # from W = 0 the rank overshoots (789 at step 50) and decays: 166 at step 320, 127 at step 520, 116 at
-               # step 640 (DLCO_EIG_DEBUG trace, gpurun_out/c3_dbg2.err): the named regime, rank ~128, is reached
+               # step 640 (DLCO_EIG_DEBUG trace, profiles/r2_c3_rank_trajectory.txt): the named regime, rank ~128, is reached
                # after ~500 steps, and before that every step still takes 2-3 tracker passes on a block of 192+ rows
                rank_band=(100, 160), fpr95_band=(0.02, 0.15), burn_in=500),
 }

@@ -229,6 +229,8 @@ size_t jacobi_work_floats(int n);
 constexpr int CHOL_INV_MAX_N = 128;
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s);
 // row norms of (Y - theta_i X) and of X
+// n floats -> pinned host memory, then *flag_host = seq with system-scope release (the host polls flag_host)
+void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s);
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
 void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);

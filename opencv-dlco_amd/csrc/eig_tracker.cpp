@@ -2,6 +2,7 @@
 #include "eig_tracker.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <initializer_list>
@@ -45,8 +46,9 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     slab_floats_ = std::min(slab_floats_, (size_t)64 << 20);
     slab_floats_ = std::max(slab_floats_, (size_t)cap_ * F_);
     slab_.alloc(slab_floats_);
-    pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats)
+    pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats); the last 16 hold the poll flag
     DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float)));
+    std::memset(pin_, 0, pin_floats_ * sizeof(float));
     h_theta_.assign(cap_, 0.f);
     h_res_.assign(cap_, 0.f);
 }
@@ -444,8 +446,26 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         y_ok_ = true;                                                // Y_ = Q_ H for the current H
         residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
         const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
-        DLCO_HIP(hipMemcpyAsync(pin_, ritz_block_.p, blk * sizeof(float), hipMemcpyDeviceToHost, s_));
-        DLCO_HIP(hipStreamSynchronize(s_));
+        if (poll_readback_) {
+            // the block is written into pinned memory by a kernel that raises a sequence number last; polling it
+            // costs a few microseconds where copy + hipStreamSynchronize cost tens (one read-back per pass)
+            unsigned *flag = reinterpret_cast<unsigned *>(pin_ + pin_floats_ - 16);
+            const unsigned seq = ++publish_seq_;
+            publish_block(ritz_block_.p, pin_, (int)blk, flag, seq, s_);
+            const auto t0 = std::chrono::steady_clock::now();
+            bool seen = false;
+            for (long spins = 0;; spins++) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            }
+            if (!seen) {                                             // slow box or a faulted kernel: let the runtime tell
+                DLCO_HIP(hipStreamSynchronize(s_));
+                DLCO_CHECK(__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq, -3, "eig tracker: read-back did not arrive");
+            }
+        } else {
+            DLCO_HIP(hipMemcpyAsync(pin_, ritz_block_.p, blk * sizeof(float), hipMemcpyDeviceToHost, s_));
+            DLCO_HIP(hipStreamSynchronize(s_));
+        }
         std::memcpy(h_theta_.data(), pin_, (size_t)m_ * sizeof(float));
         std::memcpy(h_res_.data(), pin_ + (cap_ + 8), (size_t)m_ * sizeof(float));
         st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * (cap_ + 8));

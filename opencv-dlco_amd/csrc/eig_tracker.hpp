@@ -97,6 +97,8 @@ private:
     std::vector<float> h_theta_, h_res_, h_tmp_, h_sc_;
     std::vector<int32_t> h_sr_;
     float *pin_ = nullptr;           // pinned host staging
+    unsigned publish_seq_ = 0;
+    bool poll_readback_ = std::getenv("DLCO_SYNC_READBACK") == nullptr;
     size_t pin_floats_ = 0;
     EigStats st_;
     Profiler *prof_ = nullptr;
