@@ -18,6 +18,9 @@
 // (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain).
 #include "dlco_internal.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace dlco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,6 +50,7 @@ struct SyrkDev {
     int nt;                       // tiles per edge
     int slab_t0, slab_nt;         // column-slab mode: tile columns [slab_t0, slab_t0 + slab_nt) only
     int stagger_from, stagger_units;   // workgroups [from, 2*from) sleep units * nk * 4096 cycles at start
+    const int32_t *tile_map;      // tile number -> (bi << 16 | bj), see syrk_tile_map()
 };
 
 union SyrkLds {
@@ -76,18 +80,10 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;     // bijective remap
     }
-    int bi = 0, bj = 0;
-    if (SLAB) {
-        bi = t / g.slab_nt;                                   // neighbours share the row panel
-        bj = g.slab_t0 + t % g.slab_nt;
-    } else {
-        // row-major enumeration of (bi <= bj): solve offset(bi) = bi*nt - bi*(bi-1)/2 <= t
-        float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
-        bi = max(0, min(g.nt - 1, (int)fb));
-        while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
-        while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
-        bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
-    }
+    // the tile list walks 8 x 8 super-blocks of tiles (syrk_tile_map): the ~64 tiles an XCD runs at a time then
+    // need 8 + 8 row panels of the gathered rows (2.5 MB at K = 305) instead of 1 + 64 (10 MB > its 4 MB L2)
+    const int code = g.tile_map[t];
+    const int bi = code >> 16, bj = code & 0xffff;
     const int i0 = bi * TB, j0 = bj * TB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -353,16 +349,9 @@ __device__ __forceinline__ void syrk_drain(const SyrkDev &g, const float (*T)[TL
 template <bool SLAB>
 __device__ __forceinline__ void syrk_tile(const SyrkDev &g, int t, int &bi, int &bj)
 {
-    if (SLAB) {
-        bi = t / g.slab_nt;
-        bj = g.slab_t0 + t % g.slab_nt;
-    } else {
-        float fb = ((2.f * g.nt + 1.f) - sqrtf((2.f * g.nt + 1.f) * (2.f * g.nt + 1.f) - 8.f * (float)t)) * 0.5f;
-        bi = max(0, min(g.nt - 1, (int)fb));
-        while (bi > 0 && bi * g.nt - bi * (bi - 1) / 2 > t) bi--;
-        while ((bi + 1) * g.nt - (bi + 1) * bi / 2 <= t) bi++;
-        bj = bi + (t - (bi * g.nt - bi * (bi - 1) / 2));
-    }
+    const int code = g.tile_map[t];
+    bi = code >> 16;
+    bj = code & 0xffff;
 }
 
 // The roles are separate loops over the same tile list that meet at the same barriers: their registers
@@ -624,6 +613,34 @@ void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s)
     DLCO_HIP(hipGetLastError());
 }
 
+// Tile list of a launch: 8 x 8 super-blocks of 128 x 128 tiles in row-major order, tiles row-major inside one;
+// the symmetric matrix keeps the tiles on or above the diagonal.  Built once per shape and kept on the device.
+static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count)
+{
+    struct Entry { int nt, t0, snt, dev; int32_t *p; int n; };
+    static std::vector<Entry> cache;
+    static std::mutex mu;
+    int dev = 0;
+    DLCO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+        if (e.nt == nt && e.t0 == slab_t0 && e.snt == slab_nt && e.dev == dev) { *count = e.n; return e.p; }
+    constexpr int S = 8;
+    std::vector<int32_t> m;
+    const int c0 = slab_nt > 0 ? slab_t0 : 0, c1 = slab_nt > 0 ? slab_t0 + slab_nt : nt;
+    for (int I = 0; I < nt; I += S)
+        for (int J = c0; J < c1; J += S)
+            for (int bi = I; bi < std::min(I + S, nt); bi++)
+                for (int bj = J; bj < std::min(J + S, c1); bj++)
+                    if (slab_nt > 0 || bi <= bj) m.push_back((bi << 16) | bj);
+    Entry e{nt, slab_t0, slab_nt, dev, nullptr, (int)m.size()};
+    DLCO_HIP(hipMalloc((void **)&e.p, m.size() * sizeof(int32_t)));
+    DLCO_HIP(hipMemcpy(e.p, m.data(), m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    cache.push_back(e);
+    *count = e.n;
+    return e.p;
+}
+
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16)
 {
@@ -635,6 +652,11 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
     g.slab_t0 = slab ? slab_col0 / TB : 0; g.slab_nt = slab ? slab_cols / TB : 0;
     const int ntiles = slab ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    {
+        int n_map = 0;
+        g.tile_map = syrk_tile_map(g.nt, g.slab_t0, g.slab_nt, &n_map);
+        DLCO_CHECK(n_map == ntiles, -2, "syrk: tile map size");
+    }
     {
         static int n_cu = 0, units = -1;
         if (n_cu == 0) {
