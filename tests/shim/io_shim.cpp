@@ -64,4 +64,60 @@ int shim_write_unproj(const char *path, const float *D, const unsigned char *L, 
     return rc;
 }
 
+
+// ---- the image-set / filter-bank side of the pipeline (comp-uprjdists, comp-fulldists inputs) -------------------
+// writes one dataset of any rank with the given native type id: 0 = f32, 1 = u8, 2 = i32 (contiguous layout)
+int shim_write_nd(const char *path, int create, const char *name, int type, const void *data, int nd, const size_t *shape)
+{
+    typedef dlco_io::H5::hid_t hid_t;
+    dlco_io::H5 &h = dlco_io::h5();
+    if (!h.load()) return -1;
+    const hid_t f = create ? h.H5Fcreate(path, 2 /* H5F_ACC_TRUNC */, 0, 0) : h.H5Fopen(path, 1 /* H5F_ACC_RDWR */, 0);
+    if (f < 0) return -3;
+    unsigned long long dims[4];
+    for (int i = 0; i < nd; i++) dims[i] = shape[i];
+    const hid_t s = h.H5Screate_simple(nd, dims, nullptr);
+    const hid_t t = type == 0 ? h.native_float : (type == 1 ? h.native_uchar : h.native_int);
+    const hid_t d = h.H5Dcreate2(f, name, t, s, 0, 0, 0);
+    int rc = 0;
+    if (d < 0) rc = -4;
+    else if (h.H5Dwrite(d, t, 0, 0, 0, data) < 0) rc = -5;
+    if (d >= 0) h.H5Dclose(d);
+    h.H5Sclose(s);
+    h.H5Fclose(f);
+    return rc;
+}
+
+int shim_read_i32(const char *path, const char *name, int32_t *out, size_t cap, size_t *shape)
+{
+    try {
+        std::vector<size_t> sh;
+        std::vector<int32_t> v;
+        dlco_io::read_dataset<int32_t>(path, name, sh, v);
+        if (sh.size() > 4 || v.size() > cap) return -2;
+        for (size_t i = 0; i < sh.size(); i++) shape[i] = sh[i];
+        std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+        return (int)sh.size();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "shim_read_i32: %s\n", e.what());
+        return -1;
+    }
+}
+
+int shim_read_u8(const char *path, const char *name, unsigned char *out, size_t cap, size_t *shape)
+{
+    try {
+        std::vector<size_t> sh;
+        std::vector<uint8_t> v;
+        dlco_io::read_dataset<uint8_t>(path, name, sh, v);
+        if (sh.size() > 4 || v.size() > cap) return -2;
+        for (size_t i = 0; i < sh.size(); i++) shape[i] = sh[i];
+        std::memcpy(out, v.data(), v.size());
+        return (int)sh.size();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "shim_read_u8: %s\n", e.what());
+        return -1;
+    }
+}
+
 }

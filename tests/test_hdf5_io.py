@@ -27,6 +27,9 @@ def io(tmp_path_factory):
     L = C.CDLL(str(out))
     L.shim_read_f32.argtypes = [C.c_char_p, C.c_char_p, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.shim_write_unproj.argtypes = [C.c_char_p, f32p, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.shim_write_nd.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    L.shim_read_i32.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.shim_read_u8.argtypes = [C.c_char_p, C.c_char_p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     if not L.shim_hdf5_available():
         pytest.skip("no libhdf5 >= 1.10 on this machine")
     return L
@@ -102,3 +105,72 @@ def test_pj_learn_trains_from_a_producer_style_h5_file(io, tmp_path):
     A1 = read_f32(io, str(tmp_path / "out.h5"), "A", F * F)
     assert np.array_equal(W1, np.load(tmp_path / "out_npy" / "W.npy")) and np.array_equal(A1, np.load(tmp_path / "out_npy" / "A.npy"))
     assert W1.shape[1] == F and A1.shape == (F, F)
+
+
+def write_nd(io, path, name, arr, create=False):
+    arr = np.ascontiguousarray(arr)
+    code = {np.dtype(np.float32): 0, np.dtype(np.uint8): 1, np.dtype(np.int32): 2}[arr.dtype]
+    sh = (C.c_size_t * 4)(*arr.shape)
+    rc = io.shim_write_nd(path.encode(), 1 if create else 0, name.encode(), code, arr.ctypes.data_as(C.c_void_p), arr.ndim, sh)
+    assert rc == 0, rc
+
+
+def test_image_set_datasets_round_trip(io, tmp_path):
+    """The inputs of comp-uprjdists / comp-fulldists: "Patches" u8 [n,64,64], "Indices" i32 [pairs,4], "PRFilters"
+    f32 [rows,64,64] (src/comp-uprjdists.cpp:144-218): rank-3 datasets and the int32 type through the product's reader."""
+    rng = np.random.default_rng(8)
+    patches = rng.integers(0, 256, (9, 64, 64)).astype(np.uint8)
+    pairs = rng.integers(-5, 100000, (11, 4)).astype(np.int32)
+    filt = rng.random((8, 64, 64)).astype(np.float32)
+    path = str(tmp_path / "imageset.h5")
+    write_nd(io, path, "Patches", patches, create=True)
+    write_nd(io, path, "Indices", pairs)
+    write_nd(io, path, "PRFilters", filt)
+    sh = (C.c_size_t * 4)()
+    got_p = np.empty(patches.size, np.uint8)
+    assert io.shim_read_u8(path.encode(), b"Patches", got_p.ctypes.data_as(u8p), got_p.size, sh) == 3 and tuple(sh[:3]) == (9, 64, 64)
+    assert np.array_equal(got_p.reshape(patches.shape), patches)
+    got_i = np.empty(pairs.size, np.int32)
+    assert io.shim_read_i32(path.encode(), b"Indices", got_i.ctypes.data_as(C.POINTER(C.c_int32)), got_i.size, sh) == 2 and tuple(sh[:2]) == (11, 4)
+    assert np.array_equal(got_i.reshape(pairs.shape), pairs)
+    got_f = read_f32(io, path, "PRFilters", filt.size)
+    assert got_f.shape == (8, 64, 64) and np.array_equal(got_f, filt)
+    assert io.shim_read_i32(path.encode(), b"Missing", got_i.ctypes.data_as(C.POINTER(C.c_int32)), got_i.size, sh) == -1
+
+
+@pytest.mark.gpu
+def test_comp_uprjdists_reads_hdf5_inputs(io, tmp_path):
+    """comp-uprjdists on .h5 inputs (the reference's own container) gives the bytes of the .npy run."""
+    from test_descriptors import make_filters, make_patches
+    cli = os.path.join(ROOT, "opencv-dlco_amd", "cli")
+    subprocess.check_call(["make", "-s", "-C", cli])
+    n = 60
+    rng = np.random.default_rng(2)
+    patches = make_patches(n, seed=5)
+    PR = np.zeros((16, 4096), np.float32)
+    PR[:12] = make_filters(12, seed=4, scale=25.0)
+    w = np.array([[0.5, 0.25]], np.float32)
+    pairs = np.stack([rng.integers(0, n, 200), rng.integers(0, 7, 200), rng.integers(0, n, 200), rng.integers(0, 7, 200)], 1).astype(np.int32)
+    for sub in ("flt", "img", "prj"):
+        (tmp_path / sub).mkdir()
+    np.save(tmp_path / "flt" / "PRFilters.npy", PR.reshape(-1, 64, 64))
+    np.save(tmp_path / "img" / "Patches.npy", patches)
+    np.save(tmp_path / "img" / "Indices.npy", pairs)
+    np.save(tmp_path / "prj" / "w.npy", w)
+    write_nd(io, str(tmp_path / "flt.h5"), "PRFilters", PR.reshape(-1, 64, 64), create=True)
+    write_nd(io, str(tmp_path / "img.h5"), "Patches", patches, create=True)
+    write_nd(io, str(tmp_path / "img.h5"), "Indices", pairs)
+    write_nd(io, str(tmp_path / "prj.h5"), "w", w, create=True)
+    cu = os.path.join(cli, "comp-uprjdists")
+    a = subprocess.run([cu, str(tmp_path / "flt"), str(tmp_path / "img"), "-prj", str(tmp_path / "prj"), "-id", "0", "-out", str(tmp_path / "out_npy")],
+                       capture_output=True, text=True, timeout=600)
+    b = subprocess.run([cu, str(tmp_path / "flt.h5"), str(tmp_path / "img.h5"), "-prj", str(tmp_path / "prj.h5"), "-id", "0", "-out", str(tmp_path / "out.h5")],
+                       capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    D = np.load(tmp_path / "out_npy" / "Distance.npy")
+    got = read_f32(io, str(tmp_path / "out.h5"), "Distance", D.size)
+    assert got.shape == D.shape and np.array_equal(got, D)
+    lab = np.empty(200, np.uint8)
+    sh = (C.c_size_t * 4)()
+    assert io.shim_read_u8(str(tmp_path / "out.h5").encode(), b"Label", lab.ctypes.data_as(u8p), 200, sh) == 2
+    assert np.array_equal(lab, np.load(tmp_path / "out_npy" / "Label.npy").ravel())
