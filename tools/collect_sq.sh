@@ -15,7 +15,7 @@ d, out = sys.argv[1:3]
 R = os.environ.get("DLCO_ROUND", "r2")
 f = glob.glob(d + "/*/*counter_collection.csv")[0]
 rows = list(csv.DictReader(open(f)))
-want = {"syrk_rda": "syrk_rda_stream_kernel", "skinny_rows_kernel<3, 2>": "skinny_rows_kernel<3,2>", "skinny_rows_kernel<3, 3>": "skinny_rows_kernel<3,3>",
+want = {"syrk_rda": "syrk_rda_kernel", "skinny_rows_kernel<3, 2>": "skinny_rows_kernel<3,2>", "skinny_rows_kernel<3, 3>": "skinny_rows_kernel<3,3>",
         "jacobi_seat_kernel": "jacobi_seat_kernel", "chol_inv2_kernel": "chol_inv2_kernel"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
