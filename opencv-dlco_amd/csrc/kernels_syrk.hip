@@ -412,6 +412,189 @@ __global__ __launch_bounds__(NTH, 4) void syrk_rda_lean_kernel(SyrkDev g)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Three-workgroup form: the tile-per-workgroup kernel with 16-deep K blocks (34 KB of LDS) and the output
+// re-layout done in two halves of 64 rows through the same 34 KB, so that THREE workgroups share a CU
+// (<= 168 VGPRs): more K loops beside more epilogues at any time.  Same arithmetic, same stores.
+// ---------------------------------------------------------------------------------------------------
+union SyrkLds3 {
+    struct { float A[2][KL][LD]; float B[2][KL][LD]; } st;    // 33,792 B
+    float T[TB / 2][TLD];                                      // 33,792 B
+};
+
+template <bool PAIR, bool SLAB, bool BF16>
+__global__ __launch_bounds__(NTH, 3) void syrk_rda_kernel3(SyrkDev g)
+{
+    __shared__ __attribute__((aligned(16))) SyrkLds3 lds;
+
+    const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    const int nxcd = 8;
+    const int bid = blockIdx.x;
+    int t;
+    {
+        const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int code = g.tile_map[t];
+    const int bi = code >> 16, bj = code & 0xffff;
+    const int i0 = bi * TB, j0 = bj * TB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    const int kact = min(*g.k_dev, g.kmax);
+    const int nk = (kact + KL - 1) / KL;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const int c4 = tid & 31, rbase = tid >> 5;
+    int32_t id_nx[2], id2_nx[2];
+    float w_nx[2];
+    f32x4 ra[2], rb[2];
+    auto load_ids = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = kt * KL + rbase + 8 * u;
+            id_nx[u] = g.ids[k];
+            if (PAIR) id2_nx[u] = g.ids2[k];
+            w_nx[u] = g.w[k];
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float *row = g.D + (long)id_nx[u] * g.ldd;
+            f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
+            f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
+            if (PAIR) {
+                const float *row2 = g.D + (long)id2_nx[u] * g.ldd;
+                xa -= *reinterpret_cast<const f32x4 *>(row2 + i0 + c4 * 4);
+                xb -= *reinterpret_cast<const f32x4 *>(row2 + j0 + c4 * 4);
+            }
+            ra[u] = xa * w_nx[u];
+            rb[u] = xb;
+        }
+    };
+    auto store_rows = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            *reinterpret_cast<f32x4 *>(&lds.st.A[buf][rbase + 8 * u][c4 * 4]) = ra[u];
+            *reinterpret_cast<f32x4 *>(&lds.st.B[buf][rbase + 8 * u][c4 * 4]) = rb[u];
+        }
+    };
+
+    if (nk > 0) load_ids(0);
+    float oldv[2][2][16];
+    const bool use_old = (g.beta != 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int jl = wn * 64 + b * 32 + lr;
+                oldv[a][b][r] = use_old ? g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] : 0.f;
+            }
+    if (nk > 0) {
+        load_rows();
+        if (nk > 1) load_ids(1);
+        store_rows(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_rows();
+        if (kt + 2 < nk) load_ids(kt + 2);
+        __builtin_amdgcn_s_setprio(1);
+        if (BF16) {
+            bf16x8 a0, a1, b0, b1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 8 * lk + j;
+                a0[j] = (__bf16)lds.st.A[buf][k][wm * 64 + lr];
+                a1[j] = (__bf16)lds.st.A[buf][k][wm * 64 + 32 + lr];
+                b0[j] = (__bf16)lds.st.B[buf][k][wn * 64 + lr];
+                b1[j] = (__bf16)lds.st.B[buf][k][wn * 64 + 32 + lr];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KL / 2; kk++) {
+                const float a0 = lds.st.A[buf][2 * kk + lk][wm * 64 + lr];
+                const float a1 = lds.st.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
+                const float b0 = lds.st.B[buf][2 * kk + lk][wn * 64 + lr];
+                const float b1 = lds.st.B[buf][2 * kk + lk][wn * 64 + 32 + lr];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 1 < nk) store_rows(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool diag = !SLAB && (bi == bj);
+    if (diag) {
+        // diagonal tiles (64 of 2080): element-wise, straight from registers - the upper triangle as computed,
+        // the strictly lower one as its mirror
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int jl = wn * 64 + b * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const float o = g.alpha * acc[a][b][r] + g.beta * oldv[a][b][r];
+                    if (jl >= il) g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] = o;
+                    if (il < jl) g.C[(long)(j0 + jl) * g.ldc + (i0 + il)] = o;
+                }
+            }
+        return;
+    }
+    // two halves of 64 rows: the waves of that half lay their quadrants out in T (and store the mirrored 16-byte
+    // pieces directly), then all threads store whole 512-byte rows
+    for (int hlf = 0; hlf < 2; hlf++) {
+        if (wm == hlf) {
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const int jl = wn * 64 + b * 32 + lr;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][b][4 * q + e] + g.beta * oldv[a][b][4 * q + e];
+                        const int il0 = a * 32 + 8 * q + 4 * lk;             // row inside the half
+                        if (!SLAB) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + hlf * 64 + il0)]) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) lds.T[il0 + e][jl] = o[e];
+                    }
+                }
+        }
+        __syncthreads();
+        for (int f = tid; f < (TB / 2) * (TB / 4); f += NTH) {
+            const int il = f / (TB / 4), cc = (f % (TB / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + hlf * 64 + il) * g.ldc + (j0 + cc)]) = *reinterpret_cast<const f32x4 *>(&lds.T[il][cc]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Streaming form (default for row mode).  In the kernel above a tile is an MFMA phase followed by an HBM
 // phase, and because every tile is alike the whole chip runs the two phases in lock-step: the matrix
 // cores idle while 512 KiB of dfAvg per tile move, HBM idles during the K loops (measured: launch time
@@ -843,6 +1026,20 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         }
         n_wg = std::max(8, n_cu_s / 8 * 8);
         n_wg = std::min(n_wg, (ntiles + 7) / 8 * 8);
+    }
+    static const bool use_k3 = std::getenv("DLCO_SYRK_K3") != nullptr;
+    if (use_k3) {
+#define DLCO_SYRK_K3_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel3<P, S, H>), dim3(ntiles), dim3(NTH), 0, s, g)
+        if (bf16) {
+            if (slab) { if (ids2) DLCO_SYRK_K3_LAUNCH(true, true, true); else DLCO_SYRK_K3_LAUNCH(false, true, true); }
+            else { if (ids2) DLCO_SYRK_K3_LAUNCH(true, false, true); else DLCO_SYRK_K3_LAUNCH(false, false, true); }
+        } else {
+            if (slab) { if (ids2) DLCO_SYRK_K3_LAUNCH(true, true, false); else DLCO_SYRK_K3_LAUNCH(false, true, false); }
+            else { if (ids2) DLCO_SYRK_K3_LAUNCH(true, false, false); else DLCO_SYRK_K3_LAUNCH(false, false, false); }
+        }
+#undef DLCO_SYRK_K3_LAUNCH
+        DLCO_HIP(hipGetLastError());
+        return true;
     }
     static const bool use_lean = std::getenv("DLCO_SYRK_LEAN") != nullptr;
     if (use_lean) {
