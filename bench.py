@@ -444,6 +444,9 @@ def main():
             "peak": peak_mfma,
             "unit": "TFLOP/s",
             "frac": (ach / peak_mfma) if ach else None,
+            "note": "achieved = ALGORITHMIC flops (2*K*F^2, the dense gradient the reference forms, SURVEY 8(d)) per launch time; the kernel "
+                    "computes the tiles on or above the diagonal only and mirrors them, so frac can exceed 1 - executed_frac is what the "
+                    "matrix cores really sustain",
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s); algorithmic bytes 8*F*F + 4*K*F = %d"
                             % (traffic_src, int(8 * F * F + 4 * k_mean * F)),

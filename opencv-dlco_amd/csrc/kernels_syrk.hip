@@ -51,6 +51,8 @@ struct SyrkDev {
     int slab_t0, slab_nt;         // column-slab mode: tile columns [slab_t0, slab_t0 + slab_nt) only
     int stagger_from, stagger_units;   // workgroups [from, 2*from) sleep units * nk * 4096 cycles at start
     const int32_t *tile_map;      // tile number -> (bi << 16 | bj), see syrk_tile_map()
+    unsigned long long *trace;    // developer aid (DLCO_SYRK_TRACE): 6 words per workgroup, see syrk_rda_f32
+    int old_early, noprio;        // experiment switches of syrk_rda_kernel (DLCO_SYRK_OLD_EARLY, DLCO_SYRK_PRIO)
 };
 
 union SyrkLds {
@@ -70,6 +72,7 @@ template <bool PAIR, bool SLAB, bool BF16>
 __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
+    const unsigned long long tr0 = g.trace ? wall_clock64() : 0ull;
 
     // ---- tile assignment: XCD-contiguous chunks over the tile list --------------------------------
     const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
@@ -151,31 +154,44 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
     };
 
     if (nk > 0) load_ids(0);
-    // the tile's previous contents (dual average term) are fetched now and used in the epilogue:
-    // their HBM latency hides under the whole K loop
+    // The tile's previous contents (dual average term) are needed in the epilogue only.  A wave has one in-order
+    // counter for its loads, so requested up front they would have to arrive before the first K block's gather
+    // can be waited for (measured with DLCO_SYRK_TRACE: 15 us from the start of a workgroup to its first MFMA, during
+    // which the CU's other workgroup runs its K loop alone - and a single wave per SIMD issues MFMAs at half the
+    // pipe's rate).  They are requested inside the last K block instead: no gather follows them, and they land
+    // under that block's MFMAs.  (g.old_early restores the up-front request.)
     float oldv[2][2][16];
     const bool use_old = (g.beta != 0.f);
+    // (scalar row base + one per-lane offset: the 64 loads then need no address VGPRs, which matters here because
+    // they are issued where accumulators, staging registers and fragments are all live)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int old_lane = 4 * lk * (int)g.ldc + lr;
+    auto fetch_old = [&]() {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int jl = wn * 64 + b * 32 + lr;
-                oldv[a][b][r] = use_old ? g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] : 0.f;
-            }
+                for (int r = 0; r < 16; r++) {
+                    const float *rowb = g.C + (long)(i0 + (wave_u >> 1) * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + (j0 + (wave_u & 1) * 64 + b * 32);
+                    oldv[a][b][r] = use_old ? rowb[old_lane] : 0.f;
+                }
+    };
+    constexpr bool LATE = !BF16;      // the bf16 K loop is an eighth as long and its fragments need the registers
+    if (!LATE || g.old_early || nk == 0) fetch_old();
     if (nk > 0) {
         load_rows();
         if (nk > 1) load_ids(1);
         store_rows(0);
     }
     __syncthreads();
+    const unsigned long long tr1 = g.trace ? wall_clock64() : 0ull;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_rows();                         // data of tile kt+1 (ids already here)
         if (kt + 2 < nk) load_ids(kt + 2);                    // ids of tile kt+2
-        __builtin_amdgcn_s_setprio(1);
+        if (LATE && kt == nk - 1 && !g.old_early) fetch_old();
+        if (!g.noprio) __builtin_amdgcn_s_setprio(1);
         if (BF16) {
             // fragment of the 32x32x16 bf16 MFMA: lane (lr, lk) holds k = 8 lk .. 8 lk + 7 of row lr; the
             // k-major fp32 image is read with the same conflict-free 4-byte accesses as below
@@ -212,6 +228,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         __syncthreads();
     }
 
+    const unsigned long long tr2 = g.trace ? wall_clock64() : 0ull;
     // ---- epilogue: out = beta*old + alpha*acc on the upper tile; mirror below the diagonal -------
     // All stores are 16 bytes per lane.  The transposed copy goes straight from the accumulator
     // registers: a lane holds 4 consecutive rows of one column (regs 4g..4g+3), which are 4
@@ -249,8 +266,182 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
         }
         *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + il) * g.ldc + (j0 + c4)]) = v;
     }
+    if (g.trace && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = g.trace + (size_t)blockIdx.x * 6;
+        o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tr0; o[2] = tr1; o[3] = tr2; o[4] = wall_clock64(); o[5] = (unsigned long long)t;
+    }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Eight-wave form (default).  A single wave per SIMD issues v_mfma_f32_32x32x2_f32 at HALF the pipe's
+// rate (tools/overlap_probe.cpp: 4 workgroup-waves per CU need 292 us for what 8 do in 155 us), so with
+// four-wave workgroups the matrix cores only run at full rate while BOTH workgroups of a CU are inside
+// their K loops; whenever one of them gathers its first block or writes its tile out, the other computes
+// at half speed (DLCO_SYRK_TRACE time stamps: 37 us K loops against 17 us of MFMA work).  Here a
+// workgroup has eight waves - two per SIMD, each a 64 x 32 part of the tile - and saturates the pipe on
+// its own; two such workgroups per CU then alternate freely between K loop and memory phases.
+// Same tile order, K order, arithmetic and stores as syrk_rda_kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr int NT8 = 512;
+
+template <bool PAIR, bool SLAB, bool BF16>
+__global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
+{
+    __shared__ __attribute__((aligned(16))) SyrkLds lds;
+
+    const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    const int nxcd = 8;
+    const int bid = blockIdx.x;
+    int t;
+    {
+        const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int code = g.tile_map[t];
+    const int bi = code >> 16, bj = code & 0xffff;
+    const int i0 = bi * TB, j0 = bj * TB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;                  // rows wm*64.., columns wn*32.. of the tile
+    const int lr = lane & 31, lk = lane >> 5;
+
+    const int kact = min(*g.k_dev, g.kmax);
+    const int nk = (kact + KB - 1) / KB;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+
+    // loader mapping: 2 float4 per operand per thread; rows rbase, rbase + 16 of the K block
+    const int c4 = tid & 31, rbase = tid >> 5;
+    int32_t id_nx[2], id2_nx[2];
+    float w_nx[2];
+    f32x4 ra[2], rb[2];
+    auto load_ids = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = kt * KB + rbase + 16 * u;
+            id_nx[u] = g.ids[k];
+            if (PAIR) id2_nx[u] = g.ids2[k];
+            w_nx[u] = g.w[k];
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float *row = g.D + (long)id_nx[u] * g.ldd;
+            f32x4 xa = *reinterpret_cast<const f32x4 *>(row + i0 + c4 * 4);
+            f32x4 xb = *reinterpret_cast<const f32x4 *>(row + j0 + c4 * 4);
+            if (PAIR) {
+                const float *row2 = g.D + (long)id2_nx[u] * g.ldd;
+                xa -= *reinterpret_cast<const f32x4 *>(row2 + i0 + c4 * 4);
+                xb -= *reinterpret_cast<const f32x4 *>(row2 + j0 + c4 * 4);
+            }
+            ra[u] = xa * w_nx[u];
+            rb[u] = xb;
+        }
+    };
+    auto store_rows = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            *reinterpret_cast<f32x4 *>(&lds.st.A[buf][rbase + 16 * u][c4 * 4]) = ra[u];
+            *reinterpret_cast<f32x4 *>(&lds.st.B[buf][rbase + 16 * u][c4 * 4]) = rb[u];
+        }
+    };
+
+    if (nk > 0) load_ids(0);
+    // old tile: requested inside the last K block (see syrk_rda_kernel), scalar row base + one lane offset
+    float oldv[2][16];
+    const bool use_old = (g.beta != 0.f);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int old_lane = 4 * lk * (int)g.ldc + lr;
+    auto fetch_old = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float *rowb = g.C + (long)(i0 + (wave_u >> 2) * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + (j0 + (wave_u & 3) * 32);
+                oldv[a][r] = use_old ? rowb[old_lane] : 0.f;
+            }
+    };
+    if (nk == 0) fetch_old();
+    if (nk > 0) {
+        load_rows();
+        if (nk > 1) load_ids(1);
+        store_rows(0);
+    }
+    __syncthreads();
+    // one K block; the last one is peeled so that the old tile's 32 loads (and their addresses) exist only there
+    auto kblock = [&](int kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_rows();
+        if (kt + 2 < nk) load_ids(kt + 2);
+        if (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < KB / 16; ks++) {
+                bf16x8 a0, a1, b0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 16 * ks + 8 * lk + j;
+                    a0[j] = (__bf16)lds.st.A[buf][k][wm * 64 + lr];
+                    a1[j] = (__bf16)lds.st.A[buf][k][wm * 64 + 32 + lr];
+                    b0[j] = (__bf16)lds.st.B[buf][k][wn * 32 + lr];
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 8
+            for (int kk = 0; kk < KB / 2; kk++) {
+                const float a0 = lds.st.A[buf][2 * kk + lk][wm * 64 + lr];
+                const float a1 = lds.st.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
+                const float b0 = lds.st.B[buf][2 * kk + lk][wn * 32 + lr];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_rows(buf ^ 1);
+        __syncthreads();
+    };
+    for (int kt = 0; kt + 1 < nk; kt++) kblock(kt);
+    if (nk > 0) {
+        fetch_old();
+        kblock(nk - 1);
+    }
+
+    // ---- epilogue: as syrk_rda_kernel -----------------------------------------------------------
+    const bool diag = (bi == bj);
+    const int jl = wn * 32 + lr;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][4 * q + e] + g.beta * oldv[a][4 * q + e];
+            const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;           // rows il0 .. il0+3
+            if (!SLAB && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) lds.T[il0 + e][jl] = o[e];
+        }
+    __syncthreads();
+    for (int f = tid; f < TB * (TB / 4); f += NT8) {
+        const int il = f / (TB / 4), cc = (f % (TB / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&lds.T[il][cc]);
+        if (diag) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (cc + e < il) v[e] = lds.T[cc + e][il];
+        }
+        *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + il) * g.ldc + (j0 + cc)]) = v;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Lean form: the same tile-per-workgroup scheme cut down to FOUR workgroups per CU (16-deep K blocks:
@@ -490,18 +681,18 @@ __global__ __launch_bounds__(NTH, 3) void syrk_rda_kernel3(SyrkDev g)
     };
 
     if (nk > 0) load_ids(0);
-    float oldv[2][2][16];
+    // The tile's previous contents are fetched in the epilogue, one 32 x 32 quadrant (16 values per lane) at a time:
+    // with three workgroups per CU their latency is covered by the K loops of the other two, and 64 registers are saved.
     const bool use_old = (g.beta != 0.f);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int old_lane = 4 * lk * (int)g.ldc + lr;
+    auto fetch_old = [&](int a, int b, float (&o16)[16]) {
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int jl = wn * 64 + b * 32 + lr;
-                oldv[a][b][r] = use_old ? g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] : 0.f;
-            }
+        for (int r = 0; r < 16; r++) {
+            const float *rowb = g.C + (long)(i0 + (wave_u >> 1) * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + (j0 + (wave_u & 1) * 64 + b * 32);
+            o16[r] = use_old ? rowb[old_lane] : 0.f;
+        }
+    };
     if (nk > 0) {
         load_rows();
         if (nk > 1) load_ids(1);
@@ -512,7 +703,7 @@ __global__ __launch_bounds__(NTH, 3) void syrk_rda_kernel3(SyrkDev g)
         const int buf = kt & 1;
         if (kt + 1 < nk) load_rows();
         if (kt + 2 < nk) load_ids(kt + 2);
-        __builtin_amdgcn_s_setprio(1);
+        if (!g.noprio) __builtin_amdgcn_s_setprio(1);
         if (BF16) {
             bf16x8 a0, a1, b0, b1;
 #pragma unroll
@@ -554,10 +745,12 @@ __global__ __launch_bounds__(NTH, 3) void syrk_rda_kernel3(SyrkDev g)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const int jl = wn * 64 + b * 32 + lr;
+                float o16[16];
+                fetch_old(a, b, o16);
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int il = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const float o = g.alpha * acc[a][b][r] + g.beta * oldv[a][b][r];
+                    const float o = g.alpha * acc[a][b][r] + g.beta * o16[r];
                     if (jl >= il) g.C[(long)(i0 + il) * g.ldc + (j0 + jl)] = o;
                     if (il < jl) g.C[(long)(j0 + jl) * g.ldc + (i0 + il)] = o;
                 }
@@ -573,11 +766,13 @@ __global__ __launch_bounds__(NTH, 3) void syrk_rda_kernel3(SyrkDev g)
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const int jl = wn * 64 + b * 32 + lr;
+                    float o16[16];
+                    fetch_old(a, b, o16);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][b][4 * q + e] + g.beta * oldv[a][b][4 * q + e];
+                        for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][b][4 * q + e] + g.beta * o16[4 * q + e];
                         const int il0 = a * 32 + 8 * q + 4 * lk;             // row inside the half
                         if (!SLAB) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + hlf * 64 + il0)]) = o;
 #pragma unroll
@@ -994,6 +1189,17 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.nt = F / TB;
     g.slab_t0 = slab ? slab_col0 / TB : 0; g.slab_nt = slab ? slab_cols / TB : 0;
     const int ntiles = slab ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    static const int old_early = std::getenv("DLCO_SYRK_OLD_EARLY") ? 1 : 0, noprio = std::getenv("DLCO_SYRK_PRIO") ? 0 : 1;
+    g.old_early = old_early; g.noprio = noprio;
+    g.trace = nullptr;
+    static const char *trace_path = std::getenv("DLCO_SYRK_TRACE");          // developer aid: phase time stamps of one launch
+    static int trace_calls = 0;
+    static unsigned long long *trace_buf = nullptr;
+    const bool tracing = trace_path && !slab && !ids2 && !bf16 && ++trace_calls == 400;
+    if (tracing) {
+        DLCO_HIP(hipMalloc((void **)&trace_buf, (size_t)6 * 4096 * sizeof(unsigned long long)));
+        g.trace = trace_buf;
+    }
     {
         int n_map = 0;
         g.tile_map = syrk_tile_map(g.nt, g.slab_t0, g.slab_nt, &n_map);
@@ -1026,6 +1232,21 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         }
         n_wg = std::max(8, n_cu_s / 8 * 8);
         n_wg = std::min(n_wg, (ntiles + 7) / 8 * 8);
+    }
+    static const bool use_k8 = std::getenv("DLCO_SYRK_W4") == nullptr;         // DLCO_SYRK_W4=1: the four-wave kernel
+    static const bool other = std::getenv("DLCO_SYRK_K3") || std::getenv("DLCO_SYRK_LEAN") || std::getenv("DLCO_SYRK_STREAM");
+    if (use_k8 && !other && !tracing) {
+#define DLCO_SYRK_K8_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
+        if (bf16) {
+            if (slab) { if (ids2) DLCO_SYRK_K8_LAUNCH(true, true, true); else DLCO_SYRK_K8_LAUNCH(false, true, true); }
+            else { if (ids2) DLCO_SYRK_K8_LAUNCH(true, false, true); else DLCO_SYRK_K8_LAUNCH(false, false, true); }
+        } else {
+            if (slab) { if (ids2) DLCO_SYRK_K8_LAUNCH(true, true, false); else DLCO_SYRK_K8_LAUNCH(false, true, false); }
+            else { if (ids2) DLCO_SYRK_K8_LAUNCH(true, false, false); else DLCO_SYRK_K8_LAUNCH(false, false, false); }
+        }
+#undef DLCO_SYRK_K8_LAUNCH
+        DLCO_HIP(hipGetLastError());
+        return true;
     }
     static const bool use_k3 = std::getenv("DLCO_SYRK_K3") != nullptr;
     if (use_k3) {
@@ -1078,6 +1299,18 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     }
 #undef DLCO_SYRK_LAUNCH
     DLCO_HIP(hipGetLastError());
+    if (tracing) {
+        DLCO_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)6 * ntiles);
+        DLCO_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(trace_path, "w")) {
+            std::fprintf(f, "# workgroup xcc hw_id t_start t_kloop t_epilogue t_end tile   (wall_clock64 ticks, 100 MHz)\n");
+            for (int i = 0; i < ntiles; i++)
+                std::fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i] >> 32, h[6 * i] & 0xffffffffull, h[6 * i + 1], h[6 * i + 2], h[6 * i + 3],
+                             h[6 * i + 4], h[6 * i + 5]);
+            std::fclose(f);
+        }
+    }
     return true;
 }
 
