@@ -292,6 +292,7 @@ template <bool PAIR, bool SLAB, bool BF16>
 __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
+    const unsigned long long tr0 = g.trace ? wall_clock64() : 0ull;
 
     const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
     const int nxcd = 8;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         store_rows(0);
     }
     __syncthreads();
+    const unsigned long long tr1 = g.trace ? wall_clock64() : 0ull;
     // one K block; the last one is peeled so that the old tile's 32 loads (and their addresses) exist only there
     auto kblock = [&](int kt) {
         const int buf = kt & 1;
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         kblock(nk - 1);
     }
 
+    const unsigned long long tr2 = g.trace ? wall_clock64() : 0ull;
     // ---- epilogue: as syrk_rda_kernel -----------------------------------------------------------
     const bool diag = (bi == bj);
     const int jl = wn * 32 + lr;
@@ -440,6 +443,13 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
                 if (cc + e < il) v[e] = lds.T[cc + e][il];
         }
         *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + il) * g.ldc + (j0 + cc)]) = v;
+    }
+    if (g.trace && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = g.trace + (size_t)blockIdx.x * 6;
+        o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tr0; o[2] = tr1; o[3] = tr2; o[4] = wall_clock64(); o[5] = (unsigned long long)t;
     }
 }
 
@@ -1150,6 +1160,20 @@ void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s)
     DLCO_HIP(hipGetLastError());
 }
 
+static void syrk_dump_trace(const char *path, const unsigned long long *buf, int ntiles, hipStream_t s)
+{
+    DLCO_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)6 * ntiles);
+    DLCO_HIP(hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE *f = std::fopen(path, "w")) {
+        std::fprintf(f, "# workgroup xcc hw_id t_start t_kloop t_epilogue t_end tile   (wall_clock64 ticks, 100 MHz)\n");
+        for (int i = 0; i < ntiles; i++)
+            std::fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i] >> 32, h[6 * i] & 0xffffffffull, h[6 * i + 1], h[6 * i + 2], h[6 * i + 3],
+                         h[6 * i + 4], h[6 * i + 5]);
+        std::fclose(f);
+    }
+}
+
 // Tile list of a launch: 8 x 8 super-blocks of 128 x 128 tiles in row-major order, tiles row-major inside one;
 // the symmetric matrix keeps the tiles on or above the diagonal.  Built once per shape and kept on the device.
 static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count)
@@ -1235,7 +1259,7 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     }
     static const bool use_k8 = std::getenv("DLCO_SYRK_W4") == nullptr;         // DLCO_SYRK_W4=1: the four-wave kernel
     static const bool other = std::getenv("DLCO_SYRK_K3") || std::getenv("DLCO_SYRK_LEAN") || std::getenv("DLCO_SYRK_STREAM");
-    if (use_k8 && !other && !tracing) {
+    if (use_k8 && !other) {
 #define DLCO_SYRK_K8_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
         if (bf16) {
             if (slab) { if (ids2) DLCO_SYRK_K8_LAUNCH(true, true, true); else DLCO_SYRK_K8_LAUNCH(false, true, true); }
@@ -1246,6 +1270,7 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         }
 #undef DLCO_SYRK_K8_LAUNCH
         DLCO_HIP(hipGetLastError());
+        if (tracing) syrk_dump_trace(trace_path, trace_buf, ntiles, s);
         return true;
     }
     static const bool use_k3 = std::getenv("DLCO_SYRK_K3") != nullptr;
@@ -1299,18 +1324,7 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     }
 #undef DLCO_SYRK_LAUNCH
     DLCO_HIP(hipGetLastError());
-    if (tracing) {
-        DLCO_HIP(hipStreamSynchronize(s));
-        std::vector<unsigned long long> h((size_t)6 * ntiles);
-        DLCO_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(trace_path, "w")) {
-            std::fprintf(f, "# workgroup xcc hw_id t_start t_kloop t_epilogue t_end tile   (wall_clock64 ticks, 100 MHz)\n");
-            for (int i = 0; i < ntiles; i++)
-                std::fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i] >> 32, h[6 * i] & 0xffffffffull, h[6 * i + 1], h[6 * i + 2], h[6 * i + 3],
-                             h[6 * i + 4], h[6 * i + 5]);
-            std::fclose(f);
-        }
-    }
+    if (tracing) syrk_dump_trace(trace_path, trace_buf, ntiles, s);
     return true;
 }
 
