@@ -12,7 +12,7 @@ rows = [r for r in rows if int(r['Start_Timestamp']) <= t1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows:
     if int(r['Start_Timestamp']) >= start:
-        m = re.search(r'(\w+_kernel(<[^>]*>)?|__amd_\w+)', r['Kernel_Name'])
+        m = re.search(r'(\w+_kernel\d*(<[^>]*>)?|__amd_\w+)', r['Kernel_Name'])
         k = m.group(1) if m else r['Kernel_Name'][:40]
         agg[k][0] += 1; agg[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 tot = sum(v[1] for v in agg.values())
