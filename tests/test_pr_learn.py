@@ -112,10 +112,18 @@ def test_gpu_trajectory_is_the_oracles_bit_for_bit(dlco, ref):
     ctx.set_data(D, L)
     ix = ctx.index()
     assert ix["n_pos_trn"] == ref.split(N // 2) and ix["n_neg_trn"] == ref.split(N // 2)
+    import time
     done = 0
     for n in (1, 2, 97, 3000, 20000):          # windows of different lengths, one launch each
+        t0 = time.perf_counter()
         tr.steps(n)
+        t1 = time.perf_counter()
         ctx.steps(n)
+        ctx.state()
+        t2 = time.perf_counter()
+        if n == 20000:
+            print("pr-learn, %d iterations at F = %d: oracle (one host core) %.1f k it/s, GPU %.1f k it/s (incl. the read-back)"
+                  % (n, F, n / (t1 - t0) / 1e3, n / (t2 - t1) / 1e3))
         done += n
         a, b = tr.state(), ctx.state()
         assert a["t"] == b["t"] == done

@@ -1,11 +1,10 @@
 """Times the pr-learn stage at the reference's shape: F = 5120 pooling regions, windows of
-100 000 sequential iterations per launch (the reference's LogStep).  Prints iterations/s of the GPU path and
-of the oracle (one host core, same arithmetic) on a bounded sample."""
+100 000 sequential iterations per launch (the reference's LogStep).  Prints iterations/s of the GPU path
+(the CPU restatement is timed by tests/test_pr_learn.py::test_gpu_trajectory_is_the_oracles_bit_for_bit)."""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dlco = importlib.import_module("opencv-dlco_amd")
-from oracle import ref
 
 F, N = 5120, int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
@@ -22,9 +21,3 @@ st = ctx.state()
 dt = time.time() - t0
 print(f"pr-learn GPU: {iters} iterations in {dt:.3f} s = {iters/dt/1e3:.1f} k it/s ({1e6*dt/iters:.2f} us per iteration, "
       f"2 rows x {F*4} B each), nnz(w) = {int((st['w'] != 0).sum())}")
-tr = ref.PrTrainer(D, L, mu=0.025, gamma=0.10)
-n_cpu = 20000
-t0 = time.time()
-tr.steps(n_cpu)
-dt = time.time() - t0
-print(f"pr-learn oracle (1 core): {n_cpu} iterations in {dt:.3f} s = {n_cpu/dt/1e3:.1f} k it/s")
