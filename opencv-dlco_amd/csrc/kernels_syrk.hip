@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NTH, 2) void syrk_rda_kernel(SyrkDev g)
 // ---------------------------------------------------------------------------------------------------
 constexpr int NT8 = 512;
 
-template <bool PAIR, bool SLAB, bool BF16>
+template <bool PAIR, bool SLAB, bool BF16, int UNR = 16>
 __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
             }
         } else {
-#pragma unroll 8
+#pragma unroll UNR
             for (int kk = 0; kk < KB / 2; kk++) {
                 const float a0 = lds.st.A[buf][2 * kk + lk][wm * 64 + lr];
                 const float a1 = lds.st.A[buf][2 * kk + lk][wm * 64 + 32 + lr];
