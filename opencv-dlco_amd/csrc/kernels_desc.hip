@@ -170,7 +170,7 @@ __global__ __launch_bounds__(DT) void desc_transform_kernel(const uint8_t *patch
 }
 
 // ---- pooled descriptors: C[n][f] = sum_k PT[n][k] * Fl[f][k], both K-contiguous (K = 4096) --------------
-// 128 x 128 tile per workgroup, 4 waves of 64 x 64, v_mfma_f64_16x16x4: lane l supplies A[l%16][kq] and
+// 128 x 128 tile per workgroup, 8 waves of 64 x 32, v_mfma_f64_16x16x4: lane l supplies A[l%16][kq] and
 // B[kq][l%16] with kq = l/16 and holds C[l/16 + 4r][l%16], r = 0..3.  Within a 16-wide k chunk lane group g reads the
 // four consecutive k = 4g..4g+3 of its row as one 16-byte LDS read and MFMA step s uses element s on both
 // operands: the k order inside a chunk is permuted the same way for A and B, which a sum does not see
@@ -178,9 +178,9 @@ __global__ __launch_bounds__(DT) void desc_transform_kernel(const uint8_t *patch
 constexpr int GT = 128;                // tile edge (both sides)
 constexpr int GK = 32;                 // k per staged chunk
 constexpr int GP = GK + 4;             // LDS pitch in floats
-constexpr int GTH = 256;
+constexpr int GTH = 512;               // eight waves (two per SIMD): a single wave per SIMD does not keep the matrix pipe full
 
-__global__ __launch_bounds__(GTH) void desc_pool_kernel(const float *PT, const float *Fl, int n_rows, int F8pad, int nsel, float *desc,
+__global__ __launch_bounds__(GTH, 4) void desc_pool_kernel(const float *PT, const float *Fl, int n_rows, int F8pad, int nsel, float *desc,
                                                         long desc_ld, int tiles_f)
 {
     __shared__ float As[2][GT * GP], Bs[2][GT * GP];
@@ -192,32 +192,32 @@ __global__ __launch_bounds__(GTH) void desc_pool_kernel(const float *PT, const f
     if ((long)tn * GT >= n_rows) return;
     const float *Ag = PT + (long)tn * GT * DNP;
     const float *Bg = Fl + (long)tf * GT * DNP;
-    const int lrow = tid >> 3, lseg = tid & 7;          // loader: rows lrow + 32*u, 16-byte segment lseg
-    f32x4 ra[4], rb[4];
+    const int lrow = tid >> 3, lseg = tid & 7;          // loader: rows lrow + 64*u, 16-byte segment lseg
+    f32x4 ra[2], rb[2];
     auto gload = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            ra[u] = *reinterpret_cast<const f32x4 *>(Ag + (long)(lrow + 32 * u) * DNP + kc * GK + 4 * lseg);
-            rb[u] = *reinterpret_cast<const f32x4 *>(Bg + (long)(lrow + 32 * u) * DNP + kc * GK + 4 * lseg);
+        for (int u = 0; u < 2; u++) {
+            ra[u] = *reinterpret_cast<const f32x4 *>(Ag + (long)(lrow + 64 * u) * DNP + kc * GK + 4 * lseg);
+            rb[u] = *reinterpret_cast<const f32x4 *>(Bg + (long)(lrow + 64 * u) * DNP + kc * GK + 4 * lseg);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            *reinterpret_cast<f32x4 *>(&As[buf][(lrow + 32 * u) * GP + 4 * lseg]) = ra[u];
-            *reinterpret_cast<f32x4 *>(&Bs[buf][(lrow + 32 * u) * GP + 4 * lseg]) = rb[u];
+        for (int u = 0; u < 2; u++) {
+            *reinterpret_cast<f32x4 *>(&As[buf][(lrow + 64 * u) * GP + 4 * lseg]) = ra[u];
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(lrow + 64 * u) * GP + 4 * lseg]) = rb[u];
         }
     };
-    const int wm = (wave >> 1) * 64, wf = (wave & 1) * 64;
+    const int wm = (wave >> 2) * 64, wf = (wave & 3) * 32;       // a wave: 64 PatchTrans rows x 32 filters
     const int li = lane & 15, lg = lane >> 4;
     // the f64 MFMA leaves rows lg, lg+4, lg+8, lg+12 of its 16 x 16 result in a lane's four registers: feed
     // it the PatchTrans rows in the order 0,4,8,12,1,5,.. so that those are four CONSECUTIVE rows (bins)
     const int lrowA = 4 * (li & 3) + (li >> 2);
-    f64x4 acc[4][4];
+    f64x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2; j++) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     constexpr int NCH = DNP / GK;
     gload(0);
     lstore(0);
@@ -227,18 +227,17 @@ __global__ __launch_bounds__(GTH) void desc_pool_kernel(const float *PT, const f
         if (kc + 1 < NCH) gload(kc + 1);
 #pragma unroll
         for (int c = 0; c < GK / 16; c++) {
-            f32x4 fa[4], fb[4];
+            f32x4 fa[4], fb[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                fa[i] = *reinterpret_cast<const f32x4 *>(&As[buf][(wm + 16 * i + lrowA) * GP + 16 * c + 4 * lg]);
-                fb[i] = *reinterpret_cast<const f32x4 *>(&Bs[buf][(wf + 16 * i + li) * GP + 16 * c + 4 * lg]);
-            }
+            for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const f32x4 *>(&As[buf][(wm + 16 * i + lrowA) * GP + 16 * c + 4 * lg]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][(wf + 16 * j + li) * GP + 16 * c + 4 * lg]);
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < 2; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)fa[i][s], (double)fb[j][s], acc[i][j], 0, 0, 0);
         }
         if (kc + 1 < NCH) lstore(buf ^ 1);
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(GTH) void desc_pool_kernel(const float *PT, const f
         const long prow = n0 >> 3;
         const int b0 = n0 & 7;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 2; j++) {
             const int f = tf * GT + wf + 16 * j + li;
             if (f < nsel && n0 < n_rows) {
                 f32x4 v;
