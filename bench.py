@@ -15,7 +15,8 @@ gradient + dual average, PSD projection.  Nothing is skipped inside the timed re
 The configuration BASELINE quotes is a trainer whose learned rank has settled near 64; from
 the reference's start (W = 0, every pair violates, rank of a few hundred) that takes about 300
 iterations.  Reaching that state is part of building the workload, like generating the data:
-`--burn-in` full steps (default 300, reported in config) run before the W warm-up steps, so
+`--burn-in` full steps (default 300; 500 for --config c3, whose rank passes 128 only then; reported
+in config) run before the W warm-up steps, so
 that whatever --warmup / --steps the caller passes, the K timed steps are steps of the named
 configuration and not of the start-up transient.
 
