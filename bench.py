@@ -20,11 +20,12 @@ in config) run before the W warm-up steps, so
 that whatever --warmup / --steps the caller passes, the K timed steps are steps of the named
 configuration and not of the start-up transient.
 
-N > 1 (one process per GPU, RCCL): the headline `value` is weak scaling (per-GPU batch fixed,
-global batch N*200 + N*200) with the column-sharded dual average; the same invocation then
-measures, outside the headline's timed region and reported under `other_modes`, the literal
-contract of BASELINE configs[3] (replicated dual average + F x F all-reduce per step) and the
-same-global-batch (strong-scaling) mode of SURVEY 8(d) C4 (global 200 + 200 split over N).
+N > 1 (one process per GPU, RCCL): the headline `value` is the reference's own optimiser on N GPUs - the
+same global batch of 200 + 200 rows, split over the ranks (`"scaling": "strong"`) - with the
+column-sharded dual average; the same invocation then measures, outside the headline's timed region and
+reported under `other_modes`, the literal contract of BASELINE configs[3] (replicated dual average + F x F
+all-reduce per step, same global batch) and weak scaling (per-GPU batch fixed at 200 + 200, global batch
+N*200 + N*200: a different optimiser, so its rate is not comparable with the single-GPU number).
 
 Prints ONE JSON line on rank 0.
 """
@@ -88,21 +89,25 @@ def build_context(dlco, wl, B=None, device=0, rank=0, world=1, shard=0, data_fro
     return ctx
 
 
-def make_pair_data(F, N, P, U, seed, sigma_pos=0.35, sigma_neg=1.0, noise=0.05):
+def make_pair_data(F, N, P, U, seed, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.0):
     """Pair mode stand-in for the reference's producer (src/comp-uprjdists.cpp:260-327): P per-patch
     descriptors + the [N,4] Indices table.  Three patches per 3-D point; a descriptor is
     U^T (c_point + s * delta_patch) + noise, so that a matching pair's difference has the latent
-    spread sigma_pos and a non-matching one about sigma_neg, like the row-mode generator."""
+    spread sigma_pos and a non-matching one about sigma_neg, like the row-mode generator; `jitter` is that
+    generator's log-normal scale, drawn per 3-D point (a pair's rows cannot be scaled one by one: they are
+    differences of shared descriptors), which is what makes matches and non-matches overlap."""
     rng = np.random.default_rng(seed)
     k = U.shape[0]
     npts = P // 3
     P = 3 * npts
     point = (np.arange(P) % npts).astype(np.int32)
     centre = (rng.standard_normal((npts, k)) * (sigma_neg / np.sqrt(2.0))).astype(np.float32)
+    scale = np.exp(jitter * rng.standard_normal(npts)).astype(np.float32) if jitter > 0 else np.ones(npts, np.float32)
+    centre *= scale[:, None]
     desc = np.empty((P, F), np.float32)
     for r0 in range(0, P, 8192):
         r1 = min(P, r0 + 8192)
-        z = centre[point[r0:r1]] + (sigma_pos / np.sqrt(2.0)) * rng.standard_normal((r1 - r0, k)).astype(np.float32)
+        z = centre[point[r0:r1]] + (sigma_pos / np.sqrt(2.0)) * scale[point[r0:r1], None] * rng.standard_normal((r1 - r0, k)).astype(np.float32)
         desc[r0:r1] = z @ U + (noise / np.sqrt(2.0)) * rng.standard_normal((r1 - r0, F)).astype(np.float32)
     np.clip(desc, -1.0, 1.0, out=desc)
     a = rng.integers(0, P, N).astype(np.int64)
@@ -125,7 +130,7 @@ def pmc_traffic(F, bl):
     WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC counters cannot be read
     inside a timed run, so the figure is the committed one; it is only reported for the
     configuration it was measured on."""
-    for name in ("r2_pmc_syrk.json", "r1_pmc_syrk.json"):
+    for name in ("r3_pmc_syrk.json", "r2_pmc_syrk.json", "r1_pmc_syrk.json"):
         d = committed_profile(name)
         if d and F == 8192 and bl == 200:
             return d.get("hbm_bytes_per_launch_corrected"), name
@@ -221,6 +226,43 @@ def quality(ctx, wl, with_oracle):
     return q
 
 
+def reference_run(dlco, wl, data_ctx, iters, logstep, kw):
+    """What the pj-learn program does with its time (src/pj-learn.cpp:305-589), as opposed to the steady-state step
+    the headline times: iterations t = 0..iters from W = 0 (the start-up transient, rank of several hundred, is
+    inside), with the LogStep block - validation over the 50 000 + 50 000 held-out rows and, on a new best objective,
+    ComputePJStats over all N rows - at t = logstep, 2*logstep, ... like the reference.  Runs on a second context
+    that shares the resident Distance matrix.  Ttime / Vtime are the fields of the reference's own log lines."""
+    c2 = build_context(dlco, wl, data_from=data_ctx, **kw)
+    c2.sync()
+    windows = []
+    w0 = time.perf_counter()
+    t_train = t_log = 0.0
+    done = 0                                     # iterations run: t = 0 .. done-1
+    while done <= iters:
+        upto = min(done + logstep + (1 if done == 0 else 0), iters + 1)      # the first log comes inside iteration t = logstep
+        a = time.perf_counter()
+        c2.steps(upto - done)
+        c2.sync()
+        b = time.perf_counter()
+        t_train += b - a
+        done = upto
+        if (done - 1) % logstep != 0 or done - 1 == 0:
+            break                                # iters is not a multiple of logstep: the tail has no log line
+        e = c2.log_step()
+        c = time.perf_counter()
+        t_log += c - b
+        windows.append({"t": done - 1, "Ttime": b - a, "Vtime": c - b, "rank": e.rank, "best": bool(e.is_best)})
+    total = time.perf_counter() - w0
+    B = wl["batch"]
+    cn = c2.counters()
+    c2.close()
+    return {"value": 2.0 * B * done / total, "unit": "pair-rows/s", "iterations": done, "log_step": logstep, "seconds": total,
+            "train_seconds": t_train, "log_step_seconds": t_log, "nonconverged_steps": cn["nonconverged"],
+            "windows": windows,
+            "note": "pj-learn's own loop from W = 0: every iteration and every LogStep block inside the clock (the headline "
+                    "`value` times steady-state steps only, like the reference's Ttime per 100 steps divided out)"}
+
+
 class Runner:
     """One trainer (context + optional distributed wrapper) and its timed run."""
 
@@ -288,12 +330,17 @@ def main():
     ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default="shard",
                     help="N > 1 headline mode: column-sharded dual average (all-gathers of a few MB) or replicated "
                          "dual average with an F x F all-reduce per step")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1 headline mode: per-GPU batch fixed (weak) or global batch fixed at --batch (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1 headline mode: global batch fixed at --batch, i.e. the reference's optimiser (strong, default), "
+                         "or per-GPU batch fixed (weak: a different optimiser, reported under other_modes)")
     ap.add_argument("--no-other-modes", action="store_true", help="N > 1: measure the headline mode only")
     ap.add_argument("--bf16", action="store_true",
                     help="BASELINE configs[4] variant: the gradient SYRK on the bf16 matrix cores with fp32 accumulation "
                          "(cfg.grad_bf16; not the reference's arithmetic, gated on the FPR@95 band)")
+    ap.add_argument("--reference-iters", type=int, default=1000,
+                    help="single GPU: also time pj-learn's own loop from W = 0 for this many iterations with the LogStep block "
+                         "every --reference-logstep (reported as reference_run; 0 = skip)")
+    ap.add_argument("--reference-logstep", type=int, default=100)
     ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
     ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
     args = ap.parse_args()
@@ -347,7 +394,8 @@ def main():
         if args.pair_mode:
             ctx = dlco.Context(F, N, B=Bg, mu=wl["mu"], gamma=wl["gamma"], device=local_rank, rank=rank, world=world,
                                shard=1 if shard else 0, **kw)
-            desc, pairs = make_pair_data(F, N, args.patches, make_U(F, wl["latent"], wl["seed"]), wl["seed"])
+            desc, pairs = make_pair_data(F, N, args.patches, make_U(F, wl["latent"], wl["seed"]), wl["seed"], wl["sigma_pos"],
+                                         wl["sigma_neg"], wl["noise"], wl["jitter"])
             ctx.set_pairs(desc, pairs)                  # identical bytes on every rank (dataset replicated)
         else:
             ctx = build_context(dlco, wl, B=Bg, device=local_rank, rank=rank, world=world, shard=1 if shard else 0,
@@ -398,8 +446,9 @@ def main():
     ach = flops_launch / t_syrk / 1e12 if n_syrk else None
     peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS        # dense bf16 MFMA peak (same guide) for the --bf16 variant
     exec_flops = flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128))
+    ach_exec = exec_flops / t_syrk / 1e12 if n_syrk else None
     traffic, traffic_src = pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else (None, None)
-    sq = committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
+    sq = committed_profile("r3_pmc_sq.json") or committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
     mfma_busy = None
     try:
         mfma_busy = sq["kernels"]["syrk_rda_kernel"]["mfma_util"]
@@ -423,9 +472,10 @@ def main():
         "dtype": "bf16 (gradient MFMA inputs; f32 accumulate, f32 elsewhere)" if args.bf16 else "f32",
         "data": "synthetic",
         "config": {
-            "workload": "pj-learn %s: %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, fp32, rank %d after %d steps"
-                        % (wl["name"], N, F, B // world, B // world, B, B, wl["mu"], wl["gamma"], rank_now,
-                           args.burn_in + args.warmup + args.steps)
+            "workload": "pj-learn %s: %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, %s, rank %d after %d steps"
+                        % (wl["name"], N, F, B // world, B // world, B, B, wl["mu"], wl["gamma"],
+                           "bf16 MFMA + fp32 accumulate in the gradient, projection and statistics GEMMs (configs[4] variant), fp32 elsewhere"
+                           if args.bf16 else "fp32", rank_now, args.burn_in + args.warmup + args.steps)
                         + (" [pair mode: %d patch descriptors + Indices, differences formed in the kernels]" % args.patches
                            if args.pair_mode else ""),
             "generator": {k_: wl[k_] for k_ in ("latent", "sigma_pos", "sigma_neg", "noise", "jitter", "seed")},
@@ -441,13 +491,16 @@ def main():
         "roofline": {
             "bound": "mfma",
             "kernel": "grad_syrk_rda (fused weighted SYRK + dual average)",
-            "achieved": ach,
+            "achieved": ach_exec,
             "peak": peak_mfma,
             "unit": "TFLOP/s",
-            "frac": (ach / peak_mfma) if ach else None,
-            "note": "achieved = ALGORITHMIC flops (2*K*F^2, the dense gradient the reference forms, SURVEY 8(d)) per launch time; the kernel "
-                    "computes the tiles on or above the diagonal only and mirrors them, so frac can exceed 1 - executed_frac is what the "
-                    "matrix cores really sustain",
+            "frac": (ach_exec / peak_mfma) if ach_exec else None,
+            "note": "achieved = flops the matrix cores EXECUTE per launch (the tiles on or above the diagonal, K = rows with a non-zero "
+                    "violation count) / the launch's HIP-event time: a utilisation.  algorithmic_* is SURVEY 8(d)'s dense accounting "
+                    "(2*K*F^2 per launch, no symmetry credit) over the same time; it exceeds the executed figure by ~2x because the "
+                    "kernel never computes the lower triangle, and is NOT a utilisation",
+            "algorithmic_achieved": ach,
+            "algorithmic_frac": (ach / peak_mfma) if ach else None,
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s); algorithmic bytes 8*F*F + 4*K*F = %d"
                             % (traffic_src, int(8 * F * F + 4 * k_mean * F)),
@@ -456,8 +509,7 @@ def main():
             "algorithmic_flops_per_launch": flops_launch,
             "mean_active_rows_per_launch": k_mean,
             "executed_flops_per_launch": exec_flops,
-            # the kernel computes the upper tiles only: executed/peak is what the MFMA pipe really does
-            "executed_frac": (exec_flops / t_syrk / 1e12 / peak_mfma) if n_syrk else None,
+            "executed_frac": (ach_exec / peak_mfma) if ach_exec else None,      # = frac (kept for readers of the round-2 lines)
             "mfma_busy_frac_pmc": mfma_busy,
             # kernel path only (P1+P2+V1+Q1+U1), (ii) end to end incl. the PSD projection
             "flops_per_pair_row": flops_pair_row,
@@ -486,9 +538,9 @@ def main():
     # ---- N > 1: the other two modes SURVEY 8(d)/(e) and BASELINE configs[3] name, measured after the headline
     if world > 1 and not args.no_other_modes and not args.pair_mode:
         others = {}
-        for dp_mode, scaling in (("allreduce", "weak"), ("shard", "strong")):
+        for dp_mode, scaling in (("allreduce", "strong"), ("shard", "weak")):
             if dp_mode == R.dp_mode and scaling == R.scaling:
-                dp_mode, scaling = "shard", "weak"
+                dp_mode, scaling = "shard", "strong"
             r2 = make_runner(dp_mode, scaling, data_from=ctx)
             if r2 is None:
                 continue
@@ -501,6 +553,8 @@ def main():
                 "rank": int(r2.ctx.W().shape[0]), "nonconverged": r2.ctx.counters()["nonconverged"]}
             r2.close()
         out["other_modes"] = others
+    if world == 1 and not args.pair_mode and args.reference_iters > 0:
+        out["reference_run"] = reference_run(dlco, wl, ctx, args.reference_iters, args.reference_logstep, kw)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.pair_mode:
             out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_rows, args.cpu_steps, args.cpu_t0)

@@ -166,7 +166,11 @@ int dlco_set_allgather(dlco_ctx *ctx, dlco_allgather_fn fn, void *user);
  * a 128-byte ncclUniqueId with dlco_comm_unique_id, the host hands the same bytes to every rank
  * (MPI, torch.distributed, a file ...), and every rank calls dlco_comm_init (a collective:
  * ncclCommInitRank with cfg.rank / cfg.world).  A communicator, once created, takes precedence
- * over the callback; dlco_comm_destroy (or dlco_ctx_destroy) releases it. */
+ * over the callback; dlco_comm_destroy (or dlco_ctx_destroy) releases it.
+ * A REPLICATED context (cfg.shard = 0, world > 1) with a communicator runs the literal exchange of BASELINE configs[3]
+ * inside dlco_step: all-gather of the 2B distances, then ncclAllReduce (sum, f32) of the F x F partial gradients, then
+ * the dual average and PSD projection on every rank (= dlco_step_begin / grad / finish with the library moving the
+ * buffers).  The reference has no counterpart: it is single-device (src/pj-learn.cpp:267). */
 int dlco_comm_unique_id(void *out_id, size_t cap, const char *rccl_path);
 int dlco_comm_init(dlco_ctx *ctx, const void *id, size_t id_bytes, const char *rccl_path);
 /* Fallback transport for ranks that are processes of one node when RCCL cannot be used (no librccl, or
@@ -335,6 +339,16 @@ int  dlco_desc_pair_dists(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64
  * (Desc2 - Desc1)^2 (cuda::subtract / pow / reduce there), and Label (may be NULL) */
 int  dlco_desc_full_dists(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
                           int64_t n_pairs, float *dist_host, uint8_t *label_host);
+/* Streaming forms of the two calls above: the rows are handed to `sink` at most chunk_rows pairs at a time, in row
+ * order (row0 = first pair of the chunk; dist [rows, cols] and label [rows] are library-owned staging buffers, valid
+ * during the call only), so a tool can write each chunk as a hyperslab and check it, as the reference's loops do
+ * (src/comp-uprjdists.cpp:298-349, src/comp-fulldists.cpp:300-369), without ever holding the whole Distance matrix.
+ * A non-zero return of sink aborts the call with DLCO_ERR_INVALID. */
+typedef int (*dlco_desc_sink_fn)(void *user, int64_t row0, int64_t rows, const float *dist, const uint8_t *label);
+int  dlco_desc_pair_dists_stream(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                                 int64_t n_pairs, int64_t chunk_rows, dlco_desc_sink_fn sink, void *user);
+int  dlco_desc_full_dists_stream(dlco_desc_ctx *ctx, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                                 int64_t n_pairs, int64_t chunk_rows, dlco_desc_sink_fn sink, void *user);
 double dlco_desc_last_kernel_ms(const dlco_desc_ctx *ctx);               /* HIP-event time of the last compute call */
 
 #ifdef __cplusplus

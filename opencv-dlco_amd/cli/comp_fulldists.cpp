@@ -26,6 +26,7 @@ int main(int argc, char **argv)
     float InitSigma = 1.4f;
     bool help = false;
     const char *flt = nullptr, *img = nullptr, *dst = nullptr;
+    const size_t sChunk = 128;                              // src/comp-fulldists.cpp:61
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] == '-') {
             const bool has_val = i + 1 < argc;
@@ -78,24 +79,40 @@ int main(int argc, char **argv)
         dlco_desc_ctx *ctx = nullptr;
         if (dlco_desc_create(&ctx, InitSigma, nAngleBins, bNorm, device) != DLCO_OK) throw std::runtime_error(dlco_desc_last_error(nullptr));
         if (dlco_desc_set_filters(ctx, PRFilters.data(), (int32_t)fshape[0]) != DLCO_OK) throw std::runtime_error(dlco_desc_last_error(ctx));
-        std::vector<float> dist(npairs * regions);
-        std::vector<uint8_t> label(npairs);
-        const auto t0 = std::chrono::steady_clock::now();
-        if (dlco_desc_full_dists(ctx, patches.data(), (int64_t)pshape[0], pairs.data(), (int64_t)npairs, dist.data(), label.data()) != DLCO_OK)
-            throw std::runtime_error(dlco_desc_last_error(ctx));
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (size_t i = 0; i < dist.size(); i++)
-            if (!(dist[i] == dist[i]) || dist[i] > 3.0e38f) {                                // checkRange, :361-365
-                cout << "\nDist contains NaN\n";
-                return 255;
+        // one chunk of pairs at a time into hyperslabs of the chunked, deflate-9 datasets (src/comp-fulldists.cpp:
+        // 270-283,300-369): host memory holds one chunk, and an interrupted run keeps the rows written so far
+        struct Sink {
+            dlco_io::RowStream<uint8_t> *lab; dlco_io::RowStream<float> *dst; size_t cols, total; bool nan = false; std::string err;
+            static int put(void *u, int64_t row0, int64_t rows, const float *dist, const uint8_t *label)
+            {
+                Sink *k = static_cast<Sink *>(u);
+                try {
+                    for (size_t i = 0; i < (size_t)rows * k->cols; i++)
+                        if (!(dist[i] == dist[i]) || dist[i] > 3.0e38f) { k->nan = true; return 1; }                          // checkRange per chunk, :361-365
+                    k->lab->write_rows((size_t)row0, (size_t)rows, label);
+                    k->dst->write_rows((size_t)row0, (size_t)rows, dist);
+                } catch (const std::exception &e) { k->err = e.what(); return 2; }
+                printf("\rStep: %zu / %zu", (size_t)(row0 + rows), k->total);
+                fflush(stdout);
+                return 0;
             }
-        printf("\rStep: %zu / %zu", npairs, npairs);
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            dlco_io::Writer wr(dst);
+            dlco_io::RowStream<uint8_t> ls(wr, "Label", npairs, 1, sChunk, 1, 9);
+            dlco_io::RowStream<float> ds(wr, "Distance", npairs, regions, sChunk, 1, 9);
+            Sink k{&ls, &ds, regions, npairs};
+            const int rc = dlco_desc_full_dists_stream(ctx, patches.data(), (int64_t)pshape[0], pairs.data(), (int64_t)npairs, (int64_t)sChunk * 8,
+                                                       &Sink::put, &k);
+            if (k.nan) { cout << "\nDist contains NaN\n"; return 255; }
+            if (!k.err.empty()) throw std::runtime_error(k.err);
+            if (rc != DLCO_OK) throw std::runtime_error(dlco_desc_last_error(ctx));
+        }
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         cout << "\nDone." << endl << endl;
         printf("Total: %.09f sec\n\n", sec);
         dlco_desc_destroy(ctx);
-        dlco_io::Writer wr(dst);
-        wr.write<uint8_t>("Label", label.data(), npairs, 1);
-        wr.write<float>("Distance", dist.data(), npairs, regions);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "comp-fulldists: %s\n", e.what());
         return 2;

@@ -27,6 +27,7 @@ int main(int argc, char **argv)
     int widx = 0, device = 0;
     bool help = false;
     const char *flt = nullptr, *img = nullptr, *prj = nullptr, *out = nullptr;
+    const size_t sChunk = 128;                              // src/comp-uprjdists.cpp:68
     for (int i = 1; i < argc; i++) {
         if (argv[i][0] == '-') {
             const bool has_val = i + 1 < argc;
@@ -91,24 +92,40 @@ int main(int argc, char **argv)
         cout << "Export Pair Labels: #" << npairs << endl;
         dlco_io::term_progress(1.0, -1);
         cout << "Start Compute L1 distances." << endl;
-        std::vector<float> dist(npairs * F);
-        std::vector<uint8_t> label(npairs);
-        const auto t0 = std::chrono::steady_clock::now();
-        if (dlco_desc_pair_dists(ctx, patches.data(), (int64_t)pshape[0], pairs.data(), (int64_t)npairs, dist.data(), label.data()) != DLCO_OK)
-            throw std::runtime_error(dlco_desc_last_error(ctx));
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (size_t i = 0; i < dist.size(); i++)
-            if (!(dist[i] == dist[i]) || dist[i] > 3.0e38f || dist[i] < -3.0e38f) {         // checkRange, :341-345
-                cout << "\nDist contains NaN\n";
-                return 255;
+        // rows leave the library a chunk of sChunk pairs at a time and go straight into hyperslabs of the two chunked,
+        // deflate-9 datasets the reference creates (:254-256,289-290): host memory holds one chunk, not the matrix
+        struct Sink {
+            dlco_io::RowStream<uint8_t> *lab; dlco_io::RowStream<float> *dst; size_t cols, total; bool nan = false; std::string err;
+            static int put(void *u, int64_t row0, int64_t rows, const float *dist, const uint8_t *label)
+            {
+                Sink *k = static_cast<Sink *>(u);
+                try {
+                    for (size_t i = 0; i < (size_t)rows * k->cols; i++)
+                        if (!(dist[i] == dist[i]) || dist[i] > 3.0e38f || dist[i] < -3.0e38f) { k->nan = true; return 1; }   // checkRange per chunk, :341-345
+                    k->lab->write_rows((size_t)row0, (size_t)rows, label);
+                    k->dst->write_rows((size_t)row0, (size_t)rows, dist);
+                } catch (const std::exception &e) { k->err = e.what(); return 2; }
+                printf("\rStep: %zu / %zu", (size_t)(row0 + rows), k->total);
+                fflush(stdout);
+                return 0;
             }
-        printf("\rStep: %zu / %zu", npairs, npairs);
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            dlco_io::Writer wr(out);
+            dlco_io::RowStream<uint8_t> ls(wr, "Label", npairs, 1, sChunk, 1, 9);
+            dlco_io::RowStream<float> ds(wr, "Distance", npairs, F, sChunk, 1, 9);
+            Sink k{&ls, &ds, F, npairs};
+            const int rc = dlco_desc_pair_dists_stream(ctx, patches.data(), (int64_t)pshape[0], pairs.data(), (int64_t)npairs, (int64_t)sChunk * 64,
+                                                       &Sink::put, &k);
+            if (k.nan) { cout << "\nDist contains NaN\n"; return 255; }
+            if (!k.err.empty()) throw std::runtime_error(k.err);
+            if (rc != DLCO_OK) throw std::runtime_error(dlco_desc_last_error(ctx));
+        }
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         cout << "\nDone." << endl << endl;
         printf("Total: %.09f sec\n\n", sec);
         dlco_desc_destroy(ctx);
-        dlco_io::Writer wr(out);
-        wr.write<uint8_t>("Label", label.data(), npairs, 1);
-        wr.write<float>("Distance", dist.data(), npairs, F);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "comp-uprjdists: %s\n", e.what());
         return 2;

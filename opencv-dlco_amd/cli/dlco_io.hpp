@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -213,6 +214,79 @@ struct Writer {
     }
     void write_f32(const char *name, const float *data, size_t rows, size_t cols) { write<float>(name, data, rows, cols); }
     ~Writer() { if (f >= 0) h5().H5Fclose(f); }
+};
+
+// A 2-D dataset of known shape written a block of rows at a time, in row order: what the reference's distance
+// generators do with dscreate(rows, cols, type, name, 9, {sChunk, 1}) + one dswrite hyperslab per chunk
+// (src/comp-uprjdists.cpp:254-256,289-290,337-339).  HDF5: chunked layout {chunk_r, chunk_c}, deflate level
+// `deflate` (0 = none); a run that stops half way leaves the rows written so far.  .npy directory: the header
+// carries the final shape and the blocks are appended.
+template <typename T>
+struct RowStream {
+    std::string fpath, dname;
+    size_t rows = 0, cols = 0, next = 0;
+    bool hdf = false;
+    H5::hid_t d = -1;
+    FILE *fp = nullptr;
+    RowStream(Writer &w, const char *name, size_t rows_, size_t cols_, size_t chunk_r, size_t chunk_c, unsigned deflate)
+        : fpath(w.path), dname(name), rows(rows_), cols(cols_), hdf(is_h5(w.path))
+    {
+        if (hdf) {
+            H5 &L = h5();
+            typedef H5::hid_t hid_t;
+            auto sym = [&](const char *n) { void *q = dlsym(L.h, n); if (!q) throw std::runtime_error(std::string("libhdf5 lacks ") + n); return q; };
+            auto H5Pcreate = reinterpret_cast<hid_t (*)(hid_t)>(sym("H5Pcreate"));
+            auto H5Pset_chunk = reinterpret_cast<int (*)(hid_t, int, const unsigned long long *)>(sym("H5Pset_chunk"));
+            auto H5Pset_deflate = reinterpret_cast<int (*)(hid_t, unsigned)>(sym("H5Pset_deflate"));
+            auto H5Pclose = reinterpret_cast<int (*)(hid_t)>(sym("H5Pclose"));
+            hid_t *dcpl_cls = reinterpret_cast<hid_t *>(sym("H5P_CLS_DATASET_CREATE_ID_g"));
+            const unsigned long long dims[2] = {rows, cols};
+            const hid_t sp = L.H5Screate_simple(2, dims, nullptr);
+            hid_t pl = 0;
+            if (rows > 0 && cols > 0) {
+                const unsigned long long chunk[2] = {std::max<size_t>(1, std::min(chunk_r, rows)), std::max<size_t>(1, std::min(chunk_c, cols))};
+                pl = H5Pcreate(*dcpl_cls);
+                H5Pset_chunk(pl, 2, chunk);
+                if (deflate) H5Pset_deflate(pl, deflate);
+            }
+            d = L.H5Dcreate2(w.f, name, ElemType<T>::h5t(L), sp, 0, pl, 0);
+            if (pl) H5Pclose(pl);
+            L.H5Sclose(sp);
+            if (d < 0) throw std::runtime_error(fpath + ": cannot create dataset " + name);
+        } else {
+            const std::string f = fpath + "/" + name + ".npy";
+            npy_write(f, nullptr, ElemType<T>::npy(), 0, {rows, cols});       // header only (element size 0: no payload)
+            fp = std::fopen(f.c_str(), "ab");
+            if (!fp) throw std::runtime_error("cannot append to " + f);
+        }
+    }
+    RowStream(const RowStream &) = delete;
+    RowStream &operator=(const RowStream &) = delete;
+    void write_rows(size_t row0, size_t n, const T *data)
+    {
+        if (row0 != next || row0 + n > rows) throw std::runtime_error(fpath + ": rows of " + dname + " must be written in order");
+        next += n;
+        if (n == 0 || cols == 0) return;
+        if (hdf) {
+            H5 &L = h5();
+            auto H5Sselect_hyperslab = reinterpret_cast<int (*)(H5::hid_t, int, const unsigned long long *, const unsigned long long *,
+                                                                  const unsigned long long *, const unsigned long long *)>(dlsym(L.h, "H5Sselect_hyperslab"));
+            if (!H5Sselect_hyperslab) throw std::runtime_error("libhdf5 lacks H5Sselect_hyperslab");
+            const unsigned long long start[2] = {row0, 0}, count[2] = {n, cols};
+            const H5::hid_t fs = L.H5Dget_space(d), ms = L.H5Screate_simple(2, count, nullptr);
+            int rc = H5Sselect_hyperslab(fs, 0 /* H5S_SELECT_SET */, start, nullptr, count, nullptr);
+            if (rc >= 0) rc = L.H5Dwrite(d, ElemType<T>::h5t(L), ms, fs, 0, data);
+            L.H5Sclose(ms); L.H5Sclose(fs);
+            if (rc < 0) throw std::runtime_error(fpath + ": write of a block of " + dname + " failed");
+        } else if (std::fwrite(data, sizeof(T), n * cols, fp) != n * cols) {
+            throw std::runtime_error(fpath + ": short write of " + dname);
+        }
+    }
+    ~RowStream()
+    {
+        if (d >= 0) h5().H5Dclose(d);
+        if (fp) std::fclose(fp);
+    }
 };
 
 // Appends one f32 row to the 2-D dataset `name` of `path`, creating it with unlimited rows, chunk {1, cols}

@@ -10,14 +10,17 @@
 // -seed n, -device n.
 //
 // Multi-GPU (the reference hard-codes cuda::setDevice(0), src/pj-learn.cpp:267):
-//     -gpus N [-devices a,b,...] [-comm rccl|host]
+//     -gpus N [-devices a,b,...] [-comm rccl|host] [-dp shard|allreduce]
 // One process per GPU.  The parent loads the input once, then forks N ranks BEFORE anything has
 // touched the GPU (the children inherit the loaded rows copy-on-write); rank 0 creates the
 // ncclUniqueId, the parent relays its 128 bytes to the other ranks over pipes, and every rank runs
 // the same dlco_step loop on a column-sharded context (cfg.shard: the -batch rows per class are the
 // GLOBAL batch, split over the ranks; no F x F exchange) whose all-gathers the library issues itself
 // through RCCL (dlco_comm_init).  `-comm host` selects the library's shared-memory fallback
-// (dlco_comm_init_host) for machines without librccl or for ranks that share a device.  Rank 0 prints
+// (dlco_comm_init_host) for machines without librccl or for ranks that share a device.  `-dp allreduce`
+// is the exchange BASELINE configs[3] words: every rank keeps the whole dual average (cfg.shard = 0), the
+// library all-gathers the 2B distances and all-reduces the F x F partial gradients (ncclAllReduce) each
+// step, and the update is replicated.  Rank 0 prints
 // the log and writes the result; a rank that fails exits non-zero and the parent then stops the
 // others and exits with 3.  No process re-executes itself.
 #include "../../include/dlco.h"
@@ -45,6 +48,7 @@ struct Options {
     int gpus = 1;
     std::vector<int> devices;
     std::string comm = "rccl";
+    std::string dp = "shard";                               // multi-GPU layout: column-sharded dual average | replicated + all-reduce
     const char *src = nullptr, *dst = nullptr;
 };
 
@@ -81,7 +85,7 @@ int train(const Options &o, std::vector<float> &dists, const std::vector<uint8_t
         dlco_cfg_default(&cfg);
         cfg.F = FeatDim; cfg.N = nDists; cfg.B = (int)o.szBatch; cfg.mu = o.mu; cfg.gamma = o.gamma; cfg.seed = o.seed;
         cfg.device = world > 1 ? o.devices[rank] : o.device;
-        cfg.rank = rank; cfg.world = world; cfg.shard = world > 1 ? 1 : 0;
+        cfg.rank = rank; cfg.world = world; cfg.shard = (world > 1 && o.dp == "shard") ? 1 : 0;
         dlco_ctx *ctx = nullptr;
         if (dlco_ctx_create(&ctx, &cfg) != DLCO_OK) throw std::runtime_error(dlco_last_error(nullptr));
         if (dlco_set_data(ctx, dists.data(), labels.data()) != DLCO_OK) throw std::runtime_error(dlco_last_error(ctx));
@@ -190,6 +194,7 @@ int main(int argc, char **argv)
             if (std::strcmp(argv[i], "-device") == 0 && has_val) { o.device = atoi(argv[++i]); continue; }
             if (std::strcmp(argv[i], "-gpus") == 0 && has_val) { o.gpus = atoi(argv[++i]); continue; }
             if (std::strcmp(argv[i], "-comm") == 0 && has_val) { o.comm = argv[++i]; continue; }
+            if (std::strcmp(argv[i], "-dp") == 0 && has_val) { o.dp = argv[++i]; continue; }
             if (std::strcmp(argv[i], "-devices") == 0 && has_val) {
                 for (const char *p = argv[++i]; *p;) {
                     o.devices.push_back(atoi(p));
@@ -206,7 +211,8 @@ int main(int argc, char **argv)
         }
     }
     if (!o.src || !o.dst) help = true;
-    if (o.gpus < 1 || (o.comm != "rccl" && o.comm != "host")) help = true;
+    if (o.gpus < 1 || (o.comm != "rccl" && o.comm != "host") || (o.dp != "shard" && o.dp != "allreduce")) help = true;
+    if (o.LogStep < 1) { cout << "ERROR: -logstep must be at least 1." << endl; help = true; }
     if (o.gpus > 1) {
         if (o.devices.empty()) for (int g = 0; g < o.gpus; g++) o.devices.push_back(g);
         if ((int)o.devices.size() != o.gpus || o.szBatch % (unsigned)o.gpus != 0) {
@@ -277,6 +283,9 @@ int main(int argc, char **argv)
     dists.clear(); dists.shrink_to_fit();
     close(up[1]);
     for (int g = 1; g < N; g++) close(down_r[g]);
+    // a rank that died before reading (bad -devices entry, failed create) leaves a pipe without a reader: the relay's
+    // write must fail with EPIPE (write_exact returns false), not kill the parent, which still has to stop the others
+    signal(SIGPIPE, SIG_IGN);
     if (o.comm == "rccl") {                                    // relay the id; a rank that died simply closes its pipe
         unsigned char id[128];
         if (read_exact(up[0], id, sizeof(id)))

@@ -48,6 +48,7 @@ int main(int argc, char **argv)
         }
     }
     if (!flt || !src || !dst) help = true;
+    if (LogStep < 1) { cout << "ERROR: -logstep must be at least 1." << endl; help = true; }
     if (help) {
         cout << endl;
         cout << "Usage: pr-learn  src_h5_filter_file" << endl;
@@ -108,11 +109,11 @@ int main(int argc, char **argv)
         int nnz_best = 0;
         std::vector<float> w(FeatDim), w_Best(FeatDim, 0.f);
         unsigned t_done = 0;                                   // iterations run so far (t = 0 .. t_done-1)
+        unsigned long long next_log = LogStep;                 // t of the next log line: LogStep, 2 LogStep, ... (every t >= 1 for LogStep = 1)
         auto train_start = std::chrono::steady_clock::now();
         while (t_done <= nIter) {
             // run up to and including the next logging iteration
-            const unsigned next_log = ((t_done / LogStep) + 1) * LogStep;      // t of the next log line
-            const unsigned upto = next_log <= nIter ? next_log + 1 : nIter + 1; // iterations t < upto
+            const unsigned upto = next_log <= nIter ? (unsigned)next_log + 1 : nIter + 1; // iterations t < upto
             if (dlco_pr_steps(ctx, upto - t_done) != DLCO_OK) throw std::runtime_error(dlco_pr_last_error(ctx));
             t_done = upto;
             if (next_log > nIter) break;
@@ -124,7 +125,7 @@ int main(int argc, char **argv)
             int32_t nnz = 0;
             if (dlco_pr_validate(ctx, &LossVal, &Regul, &nnz) != DLCO_OK) throw std::runtime_error(dlco_pr_last_error(ctx));
             const double vtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - v0).count();
-            const unsigned t = next_log;
+            const unsigned t = (unsigned)next_log;
             if ((LossVal + Regul) < Obj_Best) {                // :364
                 Obj_Best = LossVal + Regul;
                 w_Best = w;
@@ -148,6 +149,7 @@ int main(int argc, char **argv)
                             (LossVal + Regul), Obj_Best, nnz, nnz_best, ttime, vtime);
             }
             cout << std::flush;
+            next_log += LogStep;
             train_start = std::chrono::steady_clock::now();
         }
         dlco_pr_destroy(ctx);

@@ -73,8 +73,11 @@ struct dlco_ctx {
     double auc_best = 0.0;
     float obj_best = FLT_MAX, fpr95_best = FLT_MAX;
     int r_best = 0;
-    std::vector<float> W_save, A_save;
-    int r_save = 0;
+    // W_Save stays in HBM; A_Save = W_Save^T W_Save is only formed when the caller asks for it (dlco_get_saved):
+    // cloning an F x F matrix to the host at every "[saved]" line cost more than the statistics pass itself
+    DevBuf<float> W_save_dev;
+    int r_save = 0;                  // rows the caller sees (F for the reference's all-zero W)
+    int r_save_dev = 0;              // rows held in W_save_dev (0 for the all-zero W)
 
     // HIP-event timers (gradient SYRK, tracker products, ...)
     Profiler prof;
@@ -128,6 +131,17 @@ void allgather(dlco_ctx *c, int32_t buffer_id, size_t bytes_per_rank)
     DLCO_CHECK(c->ag_fn != nullptr, DLCO_ERR_INVALID, "sharded step: no all-gather callback (dlco_set_allgather)");
     const int rc = c->ag_fn(c->ag_user, buffer_id, bytes_per_rank);
     if (rc != 0) throw Error(DLCO_ERR_COMM, "all-gather callback failed with code " + std::to_string(rc));
+}
+
+// Replicated dual average on several ranks (cfg.shard = 0, BASELINE configs[3] as worded): sum all-reduce of the
+// F x F partial gradients through the library's communicator
+void allreduce_grad(dlco_ctx *c)
+{
+    const size_t FF = (size_t)c->F * c->F;
+    if (c->rccl) { c->rccl->allreduce_sum_f32(c->xgrad, FF, c->stream); return; }   // ncclAllReduce over xGMI
+    if (c->hostcomm) { c->hostcomm->allreduce_sum_f32(c->xgrad, FF, c->stream); return; }
+    throw Error(DLCO_ERR_INVALID, "dlco_step: world > 1 without cfg.shard needs a communicator (dlco_comm_init / dlco_comm_init_host) "
+                                  "or the begin/grad/finish protocol");
 }
 
 void h2d(dlco_ctx *c, void *dst, const void *src, size_t bytes)
@@ -348,7 +362,10 @@ void step_finish(dlco_ctx *c)
     DLCO_HIP(hipMemcpyAsync(c->pin_k, c->k_active.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
     if (!conv) { c->nonconv_steps++; c->nonconv_window++; }
-    c->active_rows_sum += *c->pin_k;                      // update() synchronised after the copy was queued
+    // The copy above precedes, on the same stream, the kernel that publishes the tracker's Ritz block (or the
+    // block's own D2H copy): update() returns only after it has seen that block, so the count has landed.
+    // (update() always runs at least one Rayleigh-Ritz pass, i.e. one such read-back.)
+    c->active_rows_sum += *c->pin_k;
     c->steps_run++;
     c->t++;
     c->phase = 0;
@@ -479,6 +496,10 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         // eigenspace of -dfAvg has up to B dimensions (the negative rows), so the capacity follows the
         // global batch; a block that fills up nevertheless is reported as non-converged.
         const int max_rows = std::max(1024, 2 * cfg->B + 2 * c->cfg.eig_guard);
+        // the m x m solver of the Rayleigh-Ritz step (jacobi_eigh) takes at most 4096 rows: a global batch whose
+        // block could outgrow that is refused here, not in the middle of a run
+        DLCO_CHECK(std::min(c->F, max_rows) <= 4096, DLCO_ERR_INVALID,
+                   "global batch too large for the eigen tracker: 2*B + 2*eig_guard must not exceed 4096 when F > 4096");
         c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
         c->eig->set_profiler(&c->prof);
         c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
@@ -486,7 +507,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const int B = c->B;
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
         DLCO_HIP(hipHostMalloc((void **)&c->pin_ids, (size_t)2 * (2 * B + 2 * c->Bl) * sizeof(int32_t)));
-        DLCO_HIP(hipHostMalloc((void **)&c->pin_k, 4 * sizeof(int)));
+        DLCO_HIP(hipHostMalloc((void **)&c->pin_k, 4 * sizeof(int), hipHostMallocCoherent));
         c->pin_k[0] = 0;
         c->ids_all.alloc((size_t)2 * B + 2 * c->Bl);
         c->pos_rows.p = c->ids_all.p; c->neg_rows.p = c->ids_all.p + B; c->local_ids.p = c->ids_all.p + 2 * B;
@@ -666,9 +687,17 @@ int dlco_step(dlco_ctx *c)
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         if (c->shard) { step_sharded(c); return; }
-        DLCO_CHECK(c->cfg.world == 1, DLCO_ERR_INVALID,
-                   "dlco_step: world > 1 needs cfg.shard + dlco_set_allgather, or the begin/grad/finish protocol");
-        step_begin(c); step_grad(c); step_finish(c);
+        if (c->cfg.world == 1) { step_begin(c); step_grad(c); step_finish(c); return; }
+        // replicated dual average, exchanges issued by the library: all-gather of the 2B distances, then the sum
+        // all-reduce of the F x F partial gradients that BASELINE configs[3] names, then the replicated update
+        DLCO_CHECK(c->rccl || c->hostcomm, DLCO_ERR_INVALID,
+                   "dlco_step: world > 1 needs cfg.shard, or a communicator (dlco_comm_init / dlco_comm_init_host), or the "
+                   "begin/grad/finish protocol");
+        step_begin(c);
+        allgather(c, DLCO_BUF_DIST, (size_t)2 * c->Bl * sizeof(float));
+        step_grad(c);
+        allreduce_grad(c);
+        step_finish(c);
     });
 }
 
@@ -748,7 +777,7 @@ int dlco_comm_init(dlco_ctx *c, const void *id, size_t id_bytes, const char *rcc
 {
     if (!c || !id || id_bytes < 128) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
-        DLCO_CHECK(c->shard, DLCO_ERR_INVALID, "dlco_comm_init: only a sharded context (cfg.shard) exchanges through the library");
+        DLCO_CHECK(c->cfg.world > 1 || c->shard, DLCO_ERR_INVALID, "dlco_comm_init: a single-rank context has nothing to exchange");
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_comm_init: step in flight");
         DLCO_HIP(hipSetDevice(c->cfg.device));
         delete c->rccl;
@@ -761,12 +790,15 @@ int dlco_comm_init_host(dlco_ctx *c, const char *shm_name)
 {
     if (!c || !shm_name || !*shm_name) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
-        DLCO_CHECK(c->shard, DLCO_ERR_INVALID, "dlco_comm_init_host: only a sharded context (cfg.shard) exchanges through the library");
+        DLCO_CHECK(c->cfg.world > 1 || c->shard, DLCO_ERR_INVALID, "dlco_comm_init_host: a single-rank context has nothing to exchange");
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_comm_init_host: step in flight");
         DLCO_HIP(hipSetDevice(c->cfg.device));
         delete c->hostcomm;
         c->hostcomm = nullptr;
-        const size_t slot = std::max((size_t)2 * c->Bl * sizeof(float), c->comm.gather_floats * sizeof(float) / c->cfg.world);
+        // sharded: a slot holds a rank's column slab of a tracker product; replicated: a piece (<= 32 MB) of the F x F gradient
+        const size_t slab = c->shard ? c->comm.gather_floats * sizeof(float) / c->cfg.world
+                                     : std::min((size_t)c->F * c->F * sizeof(float), (size_t)32 << 20);
+        const size_t slot = std::max((size_t)2 * c->Bl * sizeof(float), slab);
         c->hostcomm = new HostComm(shm_name, c->cfg.rank, c->cfg.world, slot);
     });
 }
@@ -1059,14 +1091,13 @@ int dlco_log_step(dlco_ctx *c, dlco_log_entry *out)
             out->dim = dim; out->auc = auc; out->fpr95 = f95;
             if (c->auc_best <= auc && c->fpr95_best >= f95) {       // :558-559
                 c->auc_best = auc; c->fpr95_best = f95;
-                c->W_save.resize((size_t)std::max(rank, 1) * c->F);
-                int32_t rr = 0;
-                get_W_host(c, c->W_save.data(), &rr);
-                c->W_save.resize((size_t)rr * c->F);
-                c->r_save = rr;
-                c->A_save.resize((size_t)c->F * c->F);
-                build_A(c, c->W.p, c->r);
-                d2h(c, c->A_save.data(), c->grad.p, c->A_save.size() * sizeof(float));
+                // W_Save = W.clone(), A_Save = A.clone() (:561-562): the clone is a device copy of the rows of W
+                c->r_save_dev = c->r;
+                c->r_save = c->r > 0 ? c->r : c->F;                  // no positive eigenvalue: W = zeros(F, F), :489-490
+                if (c->r > 0) {
+                    c->W_save_dev.alloc((size_t)c->w_cap * c->F);
+                    DLCO_HIP(hipMemcpyAsync(c->W_save_dev.p, c->W.p, (size_t)c->r * c->F * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                }
                 out->saved = 1;
             }
         }
@@ -1082,11 +1113,20 @@ int dlco_get_saved(dlco_ctx *c, float *W_host, int32_t *r, float *A_host)
 {
     if (!c || !r) return DLCO_ERR_INVALID;
     *r = c->r_save;
-    if (c->r_save > 0) {
-        if (W_host) std::memcpy(W_host, c->W_save.data(), c->W_save.size() * sizeof(float));
-        if (A_host) std::memcpy(A_host, c->A_save.data(), c->A_save.size() * sizeof(float));
-    }
-    return DLCO_OK;
+    if (c->r_save <= 0 || (!W_host && !A_host)) return DLCO_OK;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_saved: step in flight");
+        const size_t FF = (size_t)c->F * c->F;
+        if (W_host) {
+            if (c->r_save_dev > 0) d2h(c, W_host, c->W_save_dev.p, (size_t)c->r_save_dev * c->F * sizeof(float));
+            else std::memset(W_host, 0, FF * sizeof(float));
+        }
+        if (A_host) {
+            build_A(c, c->W_save_dev.p, c->r_save_dev);              // A+ = W^T W (:472-478 builds the same matrix as Evec * Bmul)
+            d2h(c, A_host, c->grad.p, FF * sizeof(float));
+        }
+    });
 }
 
 int dlco_profile_enable(dlco_ctx *c, int32_t on)

@@ -266,61 +266,97 @@ int dlco_desc_compute_device(dlco_desc_ctx *c, const uint8_t *patches_host, int6
 
 // The output of comp-uprjdists: Distance [n_pairs, nsel*8] and Label [n_pairs] for pairs [n_pairs,4] =
 // (patchID1, 3DpointID1, patchID2, 3DpointID2).  Descriptors are computed once per patch.
-int dlco_desc_pair_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host, int64_t n_pairs,
-                         float *dist_host, uint8_t *label_host)
+namespace {
+// sink of the non-streaming entry points: rows land in the caller's whole-matrix buffers
+struct CopySink { float *dist; uint8_t *label; int64_t cols; };
+int copy_sink(void *user, int64_t row0, int64_t rows, const float *dist, const uint8_t *label)
 {
-    if (!c || !patches_host || !pairs_host || !dist_host || n_patches < 1 || n_pairs < 1) return DLCO_ERR_INVALID;
+    CopySink *k = static_cast<CopySink *>(user);
+    std::memcpy(k->dist + row0 * k->cols, dist, (size_t)rows * k->cols * sizeof(float));
+    if (k->label) std::memcpy(k->label + row0, label, (size_t)rows);
+    return 0;
+}
+void check_pairs(const int32_t *pairs_host, int64_t n_pairs, int64_t n_patches)
+{
+    for (int64_t i = 0; i < n_pairs; i++) {
+        const int32_t *q = pairs_host + i * 4;
+        DLCO_CHECK(q[0] >= 0 && q[0] < n_patches && q[2] >= 0 && q[2] < n_patches, DLCO_ERR_INVALID, "dlco_desc: patch id out of range");
+    }
+}
+struct PinnedStage {
+    float *dist = nullptr; uint8_t *label = nullptr;
+    PinnedStage(size_t floats, size_t labels)
+    {
+        DLCO_HIP(hipHostMalloc((void **)&dist, std::max<size_t>(floats, 1) * sizeof(float)));
+        if (hipHostMalloc((void **)&label, std::max<size_t>(labels, 1)) != hipSuccess) { (void)hipHostFree(dist); throw Error(DLCO_ERR_HIP, "hipHostMalloc failed"); }
+    }
+    ~PinnedStage() { (void)hipHostFree(dist); (void)hipHostFree(label); }
+};
+}  // namespace
+
+// comp-uprjdists' Distance / Label rows, handed to `sink` chunk_rows pairs at a time in row order: the reference
+// writes a 128-row hyperslab per chunk and checks it (src/comp-uprjdists.cpp:298-349), so its host memory stays at one
+// chunk; a whole-matrix buffer (16 GB at 500k x 8192) is only needed by callers that ask for one.
+int dlco_desc_pair_dists_stream(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                                int64_t n_pairs, int64_t chunk_rows, dlco_desc_sink_fn sink, void *user)
+{
+    if (!c || !patches_host || !pairs_host || !sink || n_patches < 1 || n_pairs < 1 || chunk_rows < 1) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         const int F = c->nsel * kBins;
-        for (int64_t i = 0; i < n_pairs; i++) {
-            const int32_t *q = pairs_host + i * 4;
-            DLCO_CHECK(q[0] >= 0 && q[0] < n_patches && q[2] >= 0 && q[2] < n_patches, DLCO_ERR_INVALID, "dlco_desc: patch id out of range");
-        }
+        check_pairs(pairs_host, n_pairs, n_patches);
         DLCO_HIP(hipSetDevice(c->device));
         DevBuf<float> table, dist;
         table.alloc((size_t)n_patches * F);
         compute(c, patches_host, n_patches, table.p, true, F);
-        const int64_t pchunk = std::max<int64_t>(1, std::min<int64_t>(n_pairs, ((int64_t)1 << 28) / F));
+        const int64_t pchunk = std::max<int64_t>(1, std::min<int64_t>(std::min(n_pairs, chunk_rows), ((int64_t)1 << 28) / F));
         DevBuf<int32_t> pairs;
         DevBuf<uint8_t> lab;
         pairs.alloc((size_t)pchunk * 4);
         lab.alloc((size_t)pchunk);
         dist.alloc((size_t)pchunk * F);
+        PinnedStage st((size_t)pchunk * F, (size_t)pchunk);
         for (int64_t p0 = 0; p0 < n_pairs; p0 += pchunk) {
             const int64_t cnt = std::min(pchunk, n_pairs - p0);
             DLCO_HIP(hipMemcpyAsync(pairs.p, pairs_host + p0 * 4, (size_t)cnt * 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             desc_pair_diff(table.p, F, F, pairs.p, cnt, dist.p, lab.p, c->stream);
-            DLCO_HIP(hipMemcpyAsync(dist_host + p0 * F, dist.p, (size_t)cnt * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            if (label_host) DLCO_HIP(hipMemcpyAsync(label_host + p0, lab.p, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+            DLCO_HIP(hipMemcpyAsync(st.dist, dist.p, (size_t)cnt * F * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            DLCO_HIP(hipMemcpyAsync(st.label, lab.p, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
             sync(c);
+            const int rc = sink(user, p0, cnt, st.dist, st.label);
+            if (rc != 0) throw Error(DLCO_ERR_INVALID, "dlco_desc: the row sink failed with code " + std::to_string(rc));
         }
     });
+}
+
+int dlco_desc_pair_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host, int64_t n_pairs,
+                         float *dist_host, uint8_t *label_host)
+{
+    if (!c || !dist_host) return DLCO_ERR_INVALID;
+    CopySink k{dist_host, label_host, (int64_t)c->nsel * kBins};
+    return dlco_desc_pair_dists_stream(c, patches_host, n_patches, pairs_host, n_pairs, (int64_t)1 << 40, copy_sink, &k);
 }
 
 // The output of comp-fulldists (src/comp-fulldists.cpp:285-369), the input of pr-learn: with ALL pooling-region
 // filters set (rows = 8 * n_regions, one row per ring replica), Distance [n_pairs, n_regions] =
 // sum over a region's 8 rows and 8 bins of (Desc2 - Desc1)^2, and Label.  A patch's full descriptor is
 // rows * 8 floats (1.3 MB at 5120 regions), so the work goes by chunks of pairs: both patches of a chunk are
-// transformed and pooled, reduced per pair, and dropped.
-int dlco_desc_full_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host, int64_t n_pairs,
-                         float *dist_host, uint8_t *label_host)
+// transformed and pooled, reduced per pair, and dropped; `sink` receives the rows of every chunk in order.
+int dlco_desc_full_dists_stream(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host,
+                                int64_t n_pairs, int64_t chunk_rows, dlco_desc_sink_fn sink, void *user)
 {
-    if (!c || !patches_host || !pairs_host || !dist_host || n_patches < 1 || n_pairs < 1) return DLCO_ERR_INVALID;
+    if (!c || !patches_host || !pairs_host || !sink || n_patches < 1 || n_pairs < 1 || chunk_rows < 1) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         DLCO_CHECK(c->nsel > 0 && c->nsel % 8 == 0, DLCO_ERR_INVALID, "dlco_desc_full_dists: the filter bank must hold 8 rows per pooling region");
         const int F = c->nsel * kBins, groups = c->nsel / 8;
-        for (int64_t i = 0; i < n_pairs; i++) {
-            const int32_t *q = pairs_host + i * 4;
-            DLCO_CHECK(q[0] >= 0 && q[0] < n_patches && q[2] >= 0 && q[2] < n_patches, DLCO_ERR_INVALID, "dlco_desc: patch id out of range");
-            if (label_host) label_host[i] = (q[1] == q[3]) ? 1 : 0;               // :268-272 of both tools
-        }
+        check_pairs(pairs_host, n_pairs, n_patches);
         DLCO_HIP(hipSetDevice(c->device));
         // pairs per chunk: 2 * chunk descriptors of F floats within ~2 GB, and within one transform chunk
-        const int64_t pchunk = std::max<int64_t>(1, std::min<int64_t>(kChunk / 2, ((int64_t)1 << 29) / ((int64_t)2 * F)));
+        const int64_t pchunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kChunk / 2, chunk_rows), ((int64_t)1 << 29) / ((int64_t)2 * F)));
         DevBuf<float> desc, dist;
         desc.alloc((size_t)2 * pchunk * F);
         dist.alloc((size_t)pchunk * groups);
         std::vector<uint8_t> stage((size_t)2 * pchunk * kPix);
+        PinnedStage st((size_t)pchunk * groups, (size_t)pchunk);
         double ms_total = 0.0;
         for (int64_t p0 = 0; p0 < n_pairs; p0 += pchunk) {
             const int64_t cnt = std::min(pchunk, n_pairs - p0);
@@ -328,15 +364,26 @@ int dlco_desc_full_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t 
                 const int32_t *q = pairs_host + (p0 + i) * 4;
                 std::memcpy(stage.data() + (size_t)i * kPix, patches_host + (size_t)q[0] * kPix, kPix);
                 std::memcpy(stage.data() + (size_t)(cnt + i) * kPix, patches_host + (size_t)q[2] * kPix, kPix);
+                st.label[i] = (q[1] == q[3]) ? 1 : 0;                              // :268-272 of both tools
             }
             compute(c, stage.data(), 2 * cnt, desc.p, true, F);
             ms_total += c->last_ms;
             desc_full_dist(desc.p, F, groups, (int)cnt, dist.p, c->stream);
-            DLCO_HIP(hipMemcpyAsync(dist_host + p0 * groups, dist.p, (size_t)cnt * groups * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            DLCO_HIP(hipMemcpyAsync(st.dist, dist.p, (size_t)cnt * groups * sizeof(float), hipMemcpyDeviceToHost, c->stream));
             sync(c);
+            const int rc = sink(user, p0, cnt, st.dist, st.label);
+            if (rc != 0) throw Error(DLCO_ERR_INVALID, "dlco_desc: the row sink failed with code " + std::to_string(rc));
         }
         c->last_ms = ms_total;
     });
+}
+
+int dlco_desc_full_dists(dlco_desc_ctx *c, const uint8_t *patches_host, int64_t n_patches, const int32_t *pairs_host, int64_t n_pairs,
+                         float *dist_host, uint8_t *label_host)
+{
+    if (!c || !dist_host) return DLCO_ERR_INVALID;
+    CopySink k{dist_host, label_host, (int64_t)c->nsel / 8};
+    return dlco_desc_full_dists_stream(c, patches_host, n_patches, pairs_host, n_pairs, (int64_t)1 << 40, copy_sink, &k);
 }
 
 // milliseconds the transform + pooling kernels of the last dlco_desc_compute* call took (HIP events)

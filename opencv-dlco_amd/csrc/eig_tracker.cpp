@@ -47,7 +47,9 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     slab_floats_ = std::max(slab_floats_, (size_t)cap_ * F_);
     slab_.alloc(slab_floats_);
     pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats); the last 16 hold the poll flag
-    DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float)));
+    // coherent (fine-grained) on purpose: the host polls a sequence number that a kernel writes with a
+    // system-scope release; with HIP_HOST_COHERENT=0 a default allocation would only be seen at a sync
+    DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float), hipHostMallocCoherent));
     std::memset(pin_, 0, pin_floats_ * sizeof(float));
     h_theta_.assign(cap_, 0.f);
     h_res_.assign(cap_, 0.f);

@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -53,6 +54,7 @@ HostComm::~HostComm()
         hdr_->failed.store(1);                                  // whoever still waits for this rank stops waiting
         munmap(hdr_, map_bytes_);
     }
+    if (sum_) (void)hipHostFree(sum_);
 }
 
 void HostComm::barrier()
@@ -95,6 +97,28 @@ void HostComm::allgather_inplace(void *buf, size_t bytes_per_rank, hipStream_t s
     }
     DLCO_HIP(hipStreamSynchronize(s));
     barrier();                                                  // every slot has been read: it may be refilled
+}
+
+void HostComm::allreduce_sum_f32(float *buf, size_t count, hipStream_t s)
+{
+    const size_t piece = slot_bytes_ / sizeof(float);
+    DLCO_CHECK(piece > 0, -6, "host transport: empty slots");
+    if (!sum_) DLCO_HIP(hipHostMalloc((void **)&sum_, slot_bytes_));
+    for (size_t o = 0; o < count; o += piece) {
+        const size_t n = std::min(piece, count - o);
+        DLCO_HIP(hipMemcpyAsync(data_ + (size_t)rank_ * slot_bytes_, buf + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        DLCO_HIP(hipStreamSynchronize(s));
+        barrier();                                              // every rank's piece is in its slot
+        const float *first = reinterpret_cast<const float *>(data_);
+        for (size_t i = 0; i < n; i++) sum_[i] = first[i];
+        for (int g = 1; g < world_; g++) {
+            const float *src = reinterpret_cast<const float *>(data_ + (size_t)g * slot_bytes_);
+            for (size_t i = 0; i < n; i++) sum_[i] += src[i];
+        }
+        DLCO_HIP(hipMemcpyAsync(buf + o, sum_, n * sizeof(float), hipMemcpyHostToDevice, s));
+        DLCO_HIP(hipStreamSynchronize(s));
+        barrier();                                              // every slot has been read: it may be refilled
+    }
 }
 
 }  // namespace dlco

@@ -22,6 +22,9 @@ public:
     // in-place all-gather of the device buffer buf viewed as [world][bytes_per_rank], ordered after the
     // work queued on s and complete (on the device) when it returns
     void allgather_inplace(void *buf, size_t bytes_per_rank, hipStream_t s);
+    // in-place sum all-reduce of `count` floats of the device buffer: slot-sized pieces go device -> segment, every rank
+    // adds the pieces of all ranks in rank order on the host (the same bits everywhere) and uploads the sum
+    void allreduce_sum_f32(float *buf, size_t count, hipStream_t s);
 
 private:
     void barrier();
@@ -31,6 +34,7 @@ private:
     size_t map_bytes_ = 0, slot_bytes_ = 0;
     int rank_ = 0, world_ = 1;
     unsigned gen_ = 0;
+    float *sum_ = nullptr;               // pinned staging of one reduced piece
 };
 
 }  // namespace dlco

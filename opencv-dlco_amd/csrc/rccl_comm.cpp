@@ -19,6 +19,7 @@ struct Api {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(comm_t *, int, UniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -49,6 +50,7 @@ Api &api(const char *lib_path)
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     a.h = h;
@@ -92,6 +94,13 @@ void RcclComm::allgather_inplace(void *buf, size_t bytes_per_rank, hipStream_t s
     // bytes are moved as ncclInt8 (= 0): the library never interprets the payload
     check(a, a.AllGather(static_cast<char *>(buf) + (size_t)rank_ * bytes_per_rank, buf, bytes_per_rank, 0, comm_, s),
           "ncclAllGather");
+}
+
+void RcclComm::allreduce_sum_f32(float *buf, size_t count, hipStream_t s)
+{
+    Api &a = api(nullptr);
+    constexpr int kFloat32 = 7, kSum = 0;                      // ncclFloat32, ncclSum (nccl.h)
+    check(a, a.AllReduce(buf, buf, count, kFloat32, kSum, comm_, s), "ncclAllReduce");
 }
 
 }  // namespace dlco

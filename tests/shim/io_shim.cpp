@@ -88,6 +88,29 @@ int shim_write_nd(const char *path, int create, const char *name, int type, cons
     return rc;
 }
 
+// the product's block-of-rows writer (dlco_io::RowStream): D [N,F] + L [N] written `block` rows at a time into chunked
+// {chunk_rows, 1} deflate-`gzip` datasets (what comp-uprjdists / comp-fulldists do); `stop_after` > 0 ends the run early
+// to show that an interrupted run keeps the rows written so far
+int shim_stream_unproj(const char *path, const float *D, const unsigned char *L, size_t N, size_t F, size_t block, size_t chunk_rows, int gzip,
+                       size_t stop_after)
+{
+    try {
+        dlco_io::Writer w(path);
+        dlco_io::RowStream<uint8_t> ls(w, "Label", N, 1, chunk_rows, 1, (unsigned)gzip);
+        dlco_io::RowStream<float> ds(w, "Distance", N, F, chunk_rows, 1, (unsigned)gzip);
+        for (size_t r0 = 0; r0 < N; r0 += block) {
+            if (stop_after && r0 >= stop_after) break;
+            const size_t n = block < N - r0 ? block : N - r0;
+            ls.write_rows(r0, n, L + r0);
+            ds.write_rows(r0, n, D + r0 * F);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "shim_stream_unproj: %s\n", e.what());
+        return -1;
+    }
+}
+
 int shim_read_i32(const char *path, const char *name, int32_t *out, size_t cap, size_t *shape)
 {
     try {

@@ -133,6 +133,31 @@ def test_pj_learn_two_processes_on_one_gpu_match_the_single_process_run(tools, d
     assert relmax(W2.T.astype(np.float64) @ W2.astype(np.float64), A2) <= 1e-5
 
 
+def test_pj_learn_two_processes_allreduce_layout_matches_the_single_process_run(tools, dataset, tmp_path):
+    """`pj-learn -gpus 2 -dp allreduce`: the exchange BASELINE configs[3] words, from C++ - every rank keeps the whole dual
+    average, the library all-gathers the 2B distances and sum-all-reduces the F x F partial gradients each step
+    (ncclAllReduce with -comm rccl; here, two ranks on the one GPU of the box, the shared-memory transport, which adds the
+    ranks' pieces in rank order).  Same global batch as the single process => same computation up to summation grouping."""
+    pj, _ = tools
+    src, D, L = dataset
+    args = ["-mu", "0.004", "-gamma", "0.5", "-iters", "100", "-batch", "40"]
+    one = subprocess.run([pj, src, str(tmp_path / "one")] + args, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr
+    two = subprocess.run([pj, src, str(tmp_path / "two"), "-gpus", "2", "-devices", "0,0", "-comm", "host", "-dp", "allreduce"] + args,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr
+    assert two.stdout.splitlines()[:13] == one.stdout.splitlines()[:13]
+    a, b = _last_entry(one.stdout), _last_entry(two.stdout)
+    assert a["t"] == b["t"] == 100 and abs(a["rank"] - b["rank"]) <= 1
+    assert abs(a["loss"] - b["loss"]) <= 0.02 * a["loss"] + 1e-5 and abs(a["regul"] - b["regul"]) <= 0.02 * a["regul"] + 1e-5
+    A1, A2 = np.load(tmp_path / "one" / "A.npy"), np.load(tmp_path / "two" / "A.npy")
+    W2 = np.load(tmp_path / "two" / "W.npy")
+    assert relmax(A2, A1) <= 2e-2                      # 100 free-running steps on either side
+    assert relmax(W2.T.astype(np.float64) @ W2.astype(np.float64), A2) <= 1e-5
+    bad = subprocess.run([pj, src, str(tmp_path / "x"), "-gpus", "2", "-dp", "bogus"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "Usage:" in bad.stdout
+
+
 def test_pj_learn_multi_process_failure_exits_nonzero(tools, dataset, tmp_path):
     """A rank that cannot start (device 99 does not exist) exits non-zero; the parent stops the other
     rank instead of leaving it in a collective, and reports failure."""
@@ -144,6 +169,49 @@ def test_pj_learn_multi_process_failure_exits_nonzero(tools, dataset, tmp_path):
     assert "rank 1" in p.stderr
     q = subprocess.run([pj, src, str(tmp_path / "bad"), "-gpus", "2", "-batch", "41"], capture_output=True, text=True, timeout=60)
     assert q.returncode == 1 and "Usage:" in q.stdout
+
+
+def test_pj_learn_rccl_rank_failure_does_not_kill_the_parent(tools, dataset, tmp_path):
+    """-comm rccl: rank 1 (device 99) dies before it reads the ncclUniqueId, so the parent's relay writes into a
+    pipe without a reader.  The parent ignores SIGPIPE, sees the failed rank, stops rank 0 (which would sit in
+    ncclCommInitRank for ever) and exits with 3 - not by signal - leaving no child behind."""
+    import ctypes.util
+    if not (ctypes.util.find_library("rccl") or os.path.exists("/opt/rocm/lib/librccl.so")):
+        pytest.skip("no librccl on this box")
+    pj, _ = tools
+    src, _, _ = dataset
+    p = subprocess.run([pj, src, str(tmp_path / "bad"), "-gpus", "2", "-devices", "0,99", "-comm", "rccl", "-iters", "100", "-batch", "40"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert "rank 1" in p.stderr
+    left = subprocess.run(["pgrep", "-x", "pj-learn"], capture_output=True, text=True)
+    assert left.stdout.strip() == "", "a rank survived its parent: " + left.stdout
+
+
+def test_pr_learn_logs_at_every_multiple_of_logstep_including_one(tmp_path):
+    """src/pr-learn.cpp:331,419-422: the step counter restarts at 0 inside the logging iteration and is incremented in
+    the same iteration, so the lines come at t = LogStep, 2 LogStep, ... - with -logstep 1 at EVERY t >= 1."""
+    subprocess.check_call(["make", "-s", "-C", CLI])
+    pr = os.path.join(CLI, "pr-learn")
+    N, F = 400, 64
+    rng = np.random.default_rng(9)
+    L = (np.arange(N) % 2 == 0).astype(np.uint8)
+    D = rng.random((N, F)).astype(np.float32)
+    D[:, :8] *= np.where(L[:, None] == 1, 0.25, 1.0).astype(np.float32)
+    flt, src = tmp_path / "filters", tmp_path / "fulldists"
+    flt.mkdir(); src.mkdir()
+    np.save(flt / "PRParams.npy", rng.integers(0, 6, (8 * F, 3)).astype(np.float32))
+    np.save(flt / "RingParams.npy", np.zeros((5, 3), np.float32))
+    np.save(src / "Distance.npy", D)
+    np.save(src / "Label.npy", L.reshape(-1, 1))
+    for logstep, iters, want in ((1, 6, [1, 2, 3, 4, 5, 6]), (3, 10, [3, 6, 9]), (4, 3, [])):
+        q = subprocess.run([pr, str(flt), str(src), str(tmp_path / ("o%d" % logstep)), "-iters", str(iters), "-logstep", str(logstep), "-maxdim", "100000"],
+                           capture_output=True, text=True, timeout=300)
+        assert q.returncode == 0, q.stderr
+        ts = [int(re.split(r"[ :]+", l)[1]) for l in q.stdout.splitlines() if l.startswith(("Best: ", "Step: "))]
+        assert ts == want, (logstep, ts)
+    z = subprocess.run([pr, str(flt), str(src), str(tmp_path / "o0"), "-logstep", "0"], capture_output=True, text=True, timeout=60)
+    assert z.returncode == 1 and "Usage:" in z.stdout
 
 
 def test_pr_learn_cli_grammar_and_saved_rows(tmp_path):

@@ -656,3 +656,40 @@ def test_uploaded_dual_average_is_symmetrised_from_its_upper_triangle(dlco):
         ctx.close()
     assert np.array_equal(outs[0], outs[0].T)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_tracker_block_above_1024_rows_and_the_batch_cap(dlco, ref):
+    """A global batch of 1100 + 1100 rows: at t = 0 (W = 0) every pair violates, the positive eigenspace of -dfAvg is
+    spanned by the ~1100 negative rows, and the tracker's block outgrows 1024 rows (the global-memory Jacobi).  One
+    teacher-forced step against the oracle's ssyevr.  A batch whose block could outgrow the 4096-row solver is refused
+    at dlco_ctx_create with a message, not in the middle of a run."""
+    N, F, B = 6000, 2048, 1100
+    D, L = synth(N, F, k=40, seed=77)
+    mu, gamma = 0.0005, 0.5
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    before = tr.state()
+    tr.step()
+    after = tr.state()
+    ctx.set_state(0, before["dfavg"], None)
+    ctx.step()
+    b = ctx.batch()
+    pr, nr = tr.batch_ids()
+    assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+    assert relmax(ctx.dfavg(), after["dfavg"]) <= 5e-6
+    W = ctx.W()
+    r = W.shape[0]
+    assert r > 900, r
+    nz = int((np.abs(W).max(axis=1) > 0).sum())
+    assert nz == r
+    assert abs(r - after["r"]) <= 2
+    err_a = relmax(ctx.A(), after["A"])
+    print("B=1100 first step: rank %d (oracle %d), err_A %.2e" % (r, after["r"], err_a))
+    assert err_a <= TOL_A
+    assert ctx.counters()["nonconverged"] == 0
+    ctx.close()
+    tr.close()
+    with pytest.raises(dlco.DlcoError) as e:
+        dlco.Context(8192, N, B=2100)
+    assert "4096" in str(e.value)

@@ -27,6 +27,7 @@ def io(tmp_path_factory):
     L = C.CDLL(str(out))
     L.shim_read_f32.argtypes = [C.c_char_p, C.c_char_p, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.shim_write_unproj.argtypes = [C.c_char_p, f32p, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.shim_stream_unproj.argtypes = [C.c_char_p, f32p, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t]
     L.shim_write_nd.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     L.shim_read_i32.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]
     L.shim_read_u8.argtypes = [C.c_char_p, C.c_char_p, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -174,3 +175,36 @@ def test_comp_uprjdists_reads_hdf5_inputs(io, tmp_path):
     sh = (C.c_size_t * 4)()
     assert io.shim_read_u8(str(tmp_path / "out.h5").encode(), b"Label", lab.ctypes.data_as(u8p), 200, sh) == 2
     assert np.array_equal(lab, np.load(tmp_path / "out_npy" / "Label.npy").ravel())
+
+
+def read_u8(io, path, name, cap):
+    out = np.empty(cap, np.uint8)
+    sh = (C.c_size_t * 4)()
+    nd = io.shim_read_u8(path.encode(), name.encode(), out.ctypes.data_as(u8p), cap, sh)
+    assert nd >= 0
+    shape = tuple(sh[i] for i in range(nd))
+    return out[:int(np.prod(shape))].reshape(shape)
+
+
+@pytest.mark.parametrize("form", ["h5", "npy"])
+def test_row_stream_writes_the_producer_layout_block_by_block(io, tmp_path, form):
+    """comp-uprjdists / comp-fulldists stream their rows chunk by chunk into {128,1} gzip-9 datasets
+    (src/comp-uprjdists.cpp:254-256,289-290,337-339) instead of holding the matrix: the product's RowStream
+    against the whole-matrix writer, ragged last block, and an interrupted run that keeps what it wrote."""
+    D, L = synth(300, 24, k=4, seed=5)
+    path = str(tmp_path / ("s.h5" if form == "h5" else "sdir"))
+    rc = io.shim_stream_unproj(path.encode(), D.ctypes.data_as(f32p), np.ascontiguousarray(L).ctypes.data_as(u8p), 300, 24, 128, 128, 9, 0)
+    assert rc == 0
+    got = read_f32(io, path, "Distance", D.size)
+    assert got.shape == (300, 24) and np.array_equal(got, D)
+    lab = read_u8(io, path, "Label", 300)
+    assert lab.shape == (300, 1) and np.array_equal(lab.ravel(), L)
+    if form == "h5":
+        out = subprocess.run(["/opt/conda/bin/h5dump", "-H", "-p", path], capture_output=True, text=True)
+        if out.returncode == 0:
+            assert "CHUNKED ( 128, 1 )" in out.stdout and "DEFLATE { LEVEL 9 }" in out.stdout
+        # stopped after the first block: the rows of that block are in the file, the rest is fill
+        path2 = str(tmp_path / "partial.h5")
+        assert io.shim_stream_unproj(path2.encode(), D.ctypes.data_as(f32p), np.ascontiguousarray(L).ctypes.data_as(u8p), 300, 24, 128, 128, 9, 128) == 0
+        part = read_f32(io, path2, "Distance", D.size)
+        assert np.array_equal(part[:128], D[:128]) and not part[128:].any()

@@ -218,14 +218,14 @@ def test_sharded_pair_mode_equals_single_rank_row_mode(dlco):
 
 
 def test_comm_init_argument_checks(dlco):
-    """dlco_comm_init is only meaningful on a sharded context and needs a full 128-byte id."""
+    """dlco_comm_init is only meaningful on a context with other ranks to talk to and needs a full 128-byte id."""
     N, F, B = 500, 128, 8
     D, L = synth(N, F, k=4, seed=60)
     ctx = dlco.Context(F, N, B=B)
     ctx.set_data(D, L)
     with pytest.raises(dlco.DlcoError) as e:
         ctx.comm_init(b"\0" * 128)
-    assert e.value.code == dlco.ERR_INVALID and "sharded" in str(e.value)
+    assert e.value.code == dlco.ERR_INVALID and "single-rank" in str(e.value)
     assert ctx.L.dlco_comm_init(ctx.h, None, 128, None) == dlco.ERR_INVALID
     ctx.step()                                            # the context is still usable
     ctx.close()
