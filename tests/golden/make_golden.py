@@ -8,11 +8,13 @@
                     reference holds (outputs of its own runs), converted from
                     HDF5 because h5py is not available on the test box.
   ref_log_head.txt  first lines of one reference log (stdout grammar fixture).
-  export_48.npz, vgg_generated_48.i.gz
-                    one "vgg_generated_XX.i" header the reference ships, with the W
-                    (from its result file) and pooling-region filters (recovered
-                    from the header itself) it was written from: golden vector of
+  export_NN.npz, vgg_generated_NN.i.gz  (NN = 48, 64, 80, 120)
+                    the four "vgg_generated_XX.i" headers the reference ships, each with
+                    the W (from its result file) and pooling-region filters (recovered
+                    from the header itself) it was written from: golden vectors of
                     the export format (see make_export_fixture).
+  pr_saved.npz      rows of "w" of three pr-learn result files with the Regul / NNZ /
+                    nzDim its logs print for them (see make_pr_saved_fixture).
   oracle_*.npz      seeded input/output vectors produced by the CPU oracle
                     (oracle/dlco_ref.c).  They pin nothing against the
                     reference by themselves; they freeze the restatement so a
@@ -185,43 +187,92 @@ def make_oracle_vectors():
     print("oracle vectors written (blas: %s)" % ref.blas_kind())
 
 
-def make_export_fixture():
-    """export_48.npz + vgg_generated_48.i.gz: a header the reference ships
-    (workspace/opencv/vgg_generated_48.i, written by its export-opencv from the W of
-    workspace/pj-learn/notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5) together with its
-    inputs: W read from that result file, and the selected pooling-region filters recovered from
-    the header's own sparse PR arrays (the filters.h5 it was made from is not in the repository).
-    Output file + inputs = a golden vector for the export format."""
+EXPORTS = {
+    # dims: (pr-learn result file, row of w, pj-learn result file) as workspace/11-opencv-export.sh:9-27 calls the tool
+    48: ("pr-learn/olderbest/yosemite-0.025-0.075-pr.h5", 7, "pj-learn/notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5"),
+    64: ("pr-learn/liberty-0.035-0.250-pr.h5", 7, "pj-learn/notredame-liberty-0.035-0.250-pr#7-0.0010-0.100-pj.h5"),
+    80: ("pr-learn/liberty-0.035-0.250-pr.h5", 7, "pj-learn/notredame-liberty-0.035-0.250-pr#7-0.0005-0.100-pj.h5"),
+    120: ("pr-learn/liberty-0.035-0.250-pr.h5", 7, "pj-learn/notredame-liberty-0.035-0.250-pr#7-0.0001-0.025-pj.h5"),
+}
+
+
+def make_export_fixture(dims=(48, 64, 80, 120)):
+    """export_NN.npz + vgg_generated_NN.i.gz: the four headers the reference ships
+    (workspace/opencv/vgg_generated_{48,64,80,120}.i, written by its export-opencv as workspace/11-opencv-export.sh
+    calls it) together with their inputs: W read from the pj-learn result file named in the header, and the selected
+    pooling-region filters recovered from the header's own sparse PR arrays (the filters.h5 they were made from is
+    not in the repository).  Output file + inputs = a golden vector for the export format."""
     import gzip
-    src = "/root/reference/workspace/opencv/vgg_generated_48.i"
-    text = open(src, "rb").read()
-    body = text.decode()
-    def ints(name):
-        m = re.search(r"static const unsigned int %s\[\] =\n\{(.*?)\};" % name, body, re.S)
-        return [int(t, 16) for t in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
-    rows = int(re.search(r"PRrows = (\d+);", body).group(1))
-    cols = int(re.search(r"PRcols = (\d+);", body).group(1))
-    idx, vals = ints("PRidx"), np.array(ints("PR"), np.uint32).view(np.float32)
-    PR = np.zeros(rows * cols, np.float32)
-    k = 0
-    for start, count in zip(idx[0::2], idx[1::2]):
-        PR[start:start + count] = vals[k:k + count]
-        k += count
-    assert k == vals.size
     read = h5_reader()
-    W = read(os.path.join(REF, "notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5"), "W")
-    np.savez_compressed(os.path.join(HERE, "export_48.npz"), PR=PR.reshape(rows, cols), W=W,
-                        prg=np.array("pr-learn/olderbest/yosemite-0.025-0.075-pr.h5"), widx=np.array(7),
-                        prj=np.array("pj-learn/notredame-yosemite-0.025-0.075-pr#7-0.0020-0.200-pj.h5"))
-    with gzip.GzipFile(os.path.join(HERE, "vgg_generated_48.i.gz"), "wb", mtime=0) as f:
-        f.write(text)
-    print("export fixture: PR", PR.reshape(rows, cols).shape, "W", W.shape, "header bytes", len(text))
+    for dim in dims:
+        prg, widx, prj = EXPORTS[dim]
+        src = "/root/reference/workspace/opencv/vgg_generated_%d.i" % dim
+        text = open(src, "rb").read()
+        body = text.decode()
+
+        def ints(name):
+            m = re.search(r"static const unsigned int %s\[\] =\n\{(.*?)\};" % name, body, re.S)
+            return [int(t, 16) for t in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
+        assert ("// PR: [%s]#%d" % (prg, widx)) in body and ("// PJ: [%s]" % prj) in body
+        rows = int(re.search(r"PRrows = (\d+);", body).group(1))
+        cols = int(re.search(r"PRcols = (\d+);", body).group(1))
+        idx, vals = ints("PRidx"), np.array(ints("PR"), np.uint32).view(np.float32)
+        PR = np.zeros(rows * cols, np.float32)
+        k = 0
+        for start, count in zip(idx[0::2], idx[1::2]):
+            PR[start:start + count] = vals[k:k + count]
+            k += count
+        assert k == vals.size
+        W = read(os.path.join("/root/reference/workspace", prj), "W")
+        assert W.shape == (dim, rows * 8)
+        np.savez_compressed(os.path.join(HERE, "export_%d.npz" % dim), PR=PR.reshape(rows, cols), W=W,
+                            prg=np.array(prg), widx=np.array(widx), prj=np.array(prj))
+        with gzip.GzipFile(os.path.join(HERE, "vgg_generated_%d.i.gz" % dim), "wb", mtime=0) as f:
+            f.write(text)
+        print("export fixture %d: PR" % dim, PR.reshape(rows, cols).shape, "W", W.shape, "header bytes", len(text))
+
+
+def make_pr_saved_fixture():
+    """pr_saved.npz: the PR stage's own record of its runs.  pr-learn appends one row to the "w" dataset of its result
+    file at every "[saved]" log line (src/pr-learn.cpp:385-400), and the "Best:" line before it prints
+    Regul = mu * sum|w| and NNZ = countNonZero(w) of that w (:358,366-369).  For three runs: the rows of "w" and, per
+    row, (t, Regul, NNZ, nzDim) as logged - a known-answer test for the regulariser / NNZ part of the oracle's
+    dlco_ref_pr_validate and the nzDim count of ComputePRStats (nzDim = 8 * NNZ, src/misc.cpp:183-193,215)."""
+    read = h5_reader()
+    base = "/root/reference/workspace/pr-learn"
+    out = {}
+    names = ["liberty-0.035-0.250-pr", "notredame-0.003-0.040-pr", "yosemite-0.025-0.075-pr"]
+    have = sorted(f[:-3] for f in os.listdir(base) if f.endswith("-pr.h5"))
+    for i, want in enumerate(names):
+        name = want if want in have else next(h for h in have if h.startswith(want.split("-")[0]))
+        lines = open(os.path.join(base, "logging", name + ".log")).read().splitlines()
+        mu = float(re.match(r"mu: (\S+) gamma: (\S+)", lines[0]).group(1))
+        rec = []
+        for j, l in enumerate(lines):
+            if l.endswith("[saved]"):
+                b = re.match(r"Best: (\d+)  Loss: (\S+) Regul: (\S+) Obj: (\S+) \((\S+)\)  NNZ: (\d+) \((\d+)\)", lines[j - 1])
+                st = re.match(r"Stat: nPR #(\d+) \(#(\d+)\) Dim/MaxDim \[(\d+)/(\d+)\]", l)
+                rec.append([int(b.group(1)), float(b.group(3)), int(b.group(6)), int(st.group(2)), int(st.group(1)), int(st.group(3))])
+        w = read(os.path.join(base, name + ".h5"), "w")
+        assert w.shape[0] == len(rec), (name, w.shape, len(rec))
+        out["p%d_name" % i] = np.array(name)
+        out["p%d_mu" % i] = np.float64(mu)
+        out["p%d_w" % i] = w
+        out["p%d_log" % i] = np.array(rec, np.float64)          # t, Regul, NNZ, nzDim, nPR, Dim
+        print("pr fixture:", name, w.shape, "mu", mu)
+    np.savez_compressed(os.path.join(HERE, "pr_saved.npz"), **out)
 
 
 if __name__ == "__main__":
-    if os.path.isdir(REF):
+    only = sys.argv[1:]                       # e.g. `make_golden.py export pr` regenerates just those fixtures
+    have_ref = os.path.isdir(REF)
+    if not have_ref:
+        print("reference not mounted: keeping the fixtures made from its files")
+    if have_ref and (not only or "results" in only):
         make_ref_results()
+    if have_ref and (not only or "export" in only):
         make_export_fixture()
-    else:
-        print("reference not mounted: keeping existing ref_results.npz")
-    make_oracle_vectors()
+    if have_ref and (not only or "pr" in only):
+        make_pr_saved_fixture()
+    if not only or "oracle" in only:
+        make_oracle_vectors()

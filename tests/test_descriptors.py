@@ -183,7 +183,7 @@ def test_transform_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,nsel", [(5, 24), (37, 200), (64, 256)])
+@pytest.mark.parametrize("n,nsel", [(5, 24), (37, 200), (64, 256), (12, 1024)])   # 1024 filters = 8192 floats per patch: the shape tools/desc_bench.py times
 def test_descriptors_match_oracle(n, nsel):
     patches, F = make_patches(n, seed=n), make_filters(nsel, seed=nsel, scale=30.0)
     ctx = dlco.DescContext()

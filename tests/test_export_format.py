@@ -1,8 +1,8 @@
 """The export wire format: `export-opencv` must reproduce, byte for byte, a
-"vgg_generated_XX.i" header that the reference ships (workspace/opencv/vgg_generated_48.i) from
+"vgg_generated_XX.i" header that the reference ships (workspace/opencv/vgg_generated_{48,64,80,120}.i) from
 the inputs it was written from — the projection W of the reference's own result file and the
-selected pooling-region filters (fixture tests/golden/export_48.npz, made by make_golden.py).
-The pooling-region selection (src/misc.cpp:78-170) is exercised by hiding the 60 selected
+selected pooling-region filters (fixtures tests/golden/export_NN.npz, made by make_golden.py).
+The pooling-region selection (src/misc.cpp:78-170) is exercised by hiding the 60 / 68 selected
 filters among duplicates, all-zero filters and filters whose learned weight is not positive."""
 import gzip
 import os
@@ -26,18 +26,19 @@ def tool():
 def _write_inputs(tmp, z, rng):
     PR, W = z["PR"], z["W"]
     n_sel, cols = PR.shape
-    nw = 10                                            # 80 filter slots, 8 per learned weight
+    gpos = (n_sel + 4 + 7) // 8                        # groups of 8 filter slots that carry a positive learned weight
+    nw = gpos + 2                                      # ... and two groups whose weight is zero / negative
     filt = np.zeros((nw * 8, cols), np.float32)
     w = np.zeros((9, nw), np.float32)                  # the tool reads row `widx` of "w"
-    slots = rng.permutation(64)                        # groups 0..7 carry a positive weight
+    slots = rng.permutation(gpos * 8)
     filt[slots[:n_sel]] = PR[rng.permutation(n_sel)]   # the selected filters, shuffled
     filt[slots[n_sel]] = PR[3]                         # duplicates of selected filters
     filt[slots[n_sel + 1]] = PR[41]
     # slots[n_sel+2:] stay all-zero filters
-    filt[64:] = rng.random((16, cols)).astype(np.float32)      # non-zero filters with weight <= 0
+    filt[gpos * 8:] = rng.random((16, cols)).astype(np.float32)      # non-zero filters with weight <= 0
     widx = int(z["widx"])
-    w[widx, :8] = rng.random(8).astype(np.float32) + 0.1
-    w[widx, 8], w[widx, 9] = 0.0, -0.5
+    w[widx, :gpos] = rng.random(gpos).astype(np.float32) + 0.1
+    w[widx, gpos], w[widx, gpos + 1] = 0.0, -0.5
     w[0, :] = 1.0                                      # another row of w must not matter
     side = int(round(np.sqrt(cols)))
     prg, prj = str(z["prg"]), str(z["prj"])
@@ -49,16 +50,19 @@ def _write_inputs(tmp, z, rng):
     return prg, widx, prj
 
 
-def test_export_reproduces_reference_header(tool, tmp_path):
-    z = np.load(os.path.join(GOLDEN, "export_48.npz"))
-    want = gzip.open(os.path.join(GOLDEN, "vgg_generated_48.i.gz"), "rb").read()
-    prg, widx, prj = _write_inputs(str(tmp_path), z, np.random.default_rng(11))
+@pytest.mark.parametrize("dim", [48, 64, 80, 120])
+def test_export_reproduces_reference_header(tool, tmp_path, dim):
+    """All four headers the reference ships (workspace/opencv/vgg_generated_{48,64,80,120}.i, workspace/11-opencv-export.sh)."""
+    z = np.load(os.path.join(GOLDEN, "export_%d.npz" % dim))
+    want = gzip.open(os.path.join(GOLDEN, "vgg_generated_%d.i.gz" % dim), "rb").read()
+    prg, widx, prj = _write_inputs(str(tmp_path), z, np.random.default_rng(11 + dim))
     out = subprocess.run([tool, "-flt", "filters.h5", "-prg", prg, "-id", str(widx), "-prj", prj, "out.i"],
                          cwd=str(tmp_path), capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "PRFilters: 60 x 4096 [480]" in out.stdout and "PJFilters: 48 x [480]" in out.stdout
+    n_sel, F = z["PR"].shape[0], z["W"].shape[1]
+    assert ("PRFilters: %d x 4096 [%d]" % (n_sel, F)) in out.stdout and ("PJFilters: %d x [%d]" % (dim, F)) in out.stdout
     got = open(os.path.join(str(tmp_path), "out.i"), "rb").read()
-    # All seven headers the reference ships end with ONE more "\n" than src/export-opencv.cpp:372-388
+    # All the headers the reference ships end with ONE more "\n" than src/export-opencv.cpp:372-388
     # writes (after the closing brace of PJ[] the source just closes the file).  This tool follows
     # the source; every byte before that final newline is identical, header comments included.
     assert want.endswith(b"\n};\n\n")

@@ -62,6 +62,29 @@ def test_reference_log_grammar_fixture():
     assert stat and all(re.match(r"^Stat: Dim \[\d+\] AUC: \d\.\d{6} \(\d\.\d{6}\) FPR95: \d+\.\d{2} \(\d+\.\d{2}\)( \[saved\])?$", l) for l in stat)
 
 
+def test_pin_split_counts_on_the_reference_log(ref):
+    """R2 (src/pj-learn.cpp:234-237: nPosTrn = size_t(|Pos| * 0.80f), float multiply then truncation) against the
+    six count lines every committed reference log prints (tests/golden/ref_log_head.txt:5-10):
+    250 000 -> 200 000 train / 50 000 validation, for the oracle's split and for the product's host-side
+    index builder (opencv-dlco_amd/csrc/pair_index.hpp through the ABI test library is GPU-side; here the oracle)."""
+    lines = open(GOLDEN + "/ref_log_head.txt").read().splitlines()
+    n = {}
+    for l in lines[4:10]:
+        m = re.match(r"^(Positive|Negative) (samples|train|valid) #(\d+)$", l)
+        assert m, l
+        n[(m.group(1), m.group(2))] = int(m.group(3))
+    for cls in ("Positive", "Negative"):
+        total, trn, val = n[(cls, "samples")], n[(cls, "train")], n[(cls, "valid")]
+        assert (total, trn, val) == (250000, 200000, 50000)
+        assert ref.split(total) == trn and total - ref.split(total) == val
+    # and through the whole index build on labels shaped like the reference's input (250k + 250k)
+    labels = (np.arange(500000) % 2 == 0).astype(np.uint8)
+    D = np.zeros((2, 4), np.float32)
+    pos, neg = ref.build_index(labels)
+    assert pos.size == neg.size == 250000
+    assert ref.split(pos.size) == 200000 and ref.split(neg.size) == 200000
+
+
 # --------------------------------------------------------------------------- frozen oracle vectors
 def test_rng_matches_frozen_vectors_and_independent_restatement(ref):
     z = golden("oracle_rng.npz")

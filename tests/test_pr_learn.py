@@ -13,7 +13,7 @@ import re
 import numpy as np
 import pytest
 
-from util import synth
+from util import golden, synth
 
 REF_LOG = "/root/reference/workspace/pr-learn/logging/liberty-0.035-0.250-pr.log"
 
@@ -100,6 +100,38 @@ def test_reference_log_grammar_of_the_pr_stage():
     assert len(body) > 100
     for l in body:
         assert best.match(l) or stat.match(l) or step.match(l), l
+
+
+def test_oracle_regulariser_and_nnz_against_the_reference_result_files(ref):
+    """Known answers the reference itself holds for this stage: every "[saved]" line of a pr-learn log has a row in the
+    "w" dataset of the matching result file (src/pr-learn.cpp:385-400), and the "Best:" line above it prints
+    Regul = mu * sum|w| (%.6f) and NNZ = countNonZero(w) of that very w (:358,366-369); the Stat line's second count
+    is nzDim = 8 rows per positive weight (src/misc.cpp:183-193).  Fixture tests/golden/pr_saved.npz (three runs,
+    24 rows).  Pins the regulariser / NNZ half of dlco_ref_pr_validate and the selection count of dlco_ref_pr_stats."""
+    z = golden("pr_saved.npz")
+    N = 40
+    rng = np.random.default_rng(0)
+    checked = 0
+    for i in range(3):
+        w_rows, log, mu = z["p%d_w" % i], z["p%d_log" % i], float(z["p%d_mu" % i])
+        F = w_rows.shape[1]
+        assert F == 5120 and len(log) == w_rows.shape[0] >= 5
+        D = rng.random((N, F)).astype(np.float32)
+        L = (np.arange(N) % 2 == 0).astype(np.uint8)
+        tr = ref.PrTrainer(D, L, mu=mu, gamma=0.25)
+        P = np.ones((8 * F, 3), np.float32)                # every pooling-region row non-zero and distinct enough for the count
+        P[:, 0] = np.arange(8 * F)
+        for w, (t, regul, nnz, nzdim, npr, dim) in zip(w_rows, log):
+            assert (w >= 0).all()                          # w = max(w, 0), :326
+            tr.set_state(int(t), w=w)
+            _, rg, nz = tr.validate()
+            assert nz == int(nnz), (str(z["p%d_name" % i]), t)
+            assert abs(rg - regul) <= 5.1e-7, (rg, regul)  # the log prints six decimals
+            st = tr.stats(P, w=w, max_dim=0)               # returns before the ROC pass (Dim > MaxDim)
+            assert st["nzdim"] == int(nzdim) == 8 * int(nnz)
+            checked += 1
+        tr.close()
+    assert checked == 24
 
 
 @pytest.mark.gpu
