@@ -59,11 +59,14 @@ typedef struct dlco_cfg {
     int32_t  strict_conv; /* 1: dlco_step returns DLCO_ERR_NOCONV when the tracker misses eig_tol (the step is
                           * still applied).  0 (default): the miss is counted (dlco_counters out[2],
                           * dlco_log_entry.nonconv) and the run goes on with the approximate W.            */
-    int32_t  grad_bf16;  /* 1: the gradient SYRK (Q1) multiplies on the bf16 matrix cores with fp32 accumulation
-                          * (operands rounded to bf16 when the MFMA fragments are read; gather, weights, dual
-                          * average stay fp32) - BASELINE configs[4].  Not the reference's arithmetic: the
-                          * result is gated on the FPR@95 band, not on the fp32 tolerances.  Needs F % 128 == 0.
-                          * 0 (default): exact fp32 MFMA.                                                    */
+    int32_t  grad_bf16;  /* 1: BASELINE configs[4], "bf16 MFMA + fp32 accumulate": every GEMM whose operand is the resident
+                          * Distance matrix multiplies on the bf16 matrix cores with fp32 accumulation, operands rounded
+                          * to bf16 once when the MFMA fragments are formed - the gradient SYRK (Q1), the projection of
+                          * the batch (P1), of the validation rows (T1) and of all N rows in the statistics pass (S2).
+                          * Gather, weights, dual average, squared sums, the PSD projection stay fp32.  Not the
+                          * reference's arithmetic: the result is gated on the FPR@95 band, not on the fp32
+                          * tolerances.  Needs F % 128 == 0.  0 (default): fp32 results (fp32 MFMA, or split-bf16
+                          * MFMA carrying all 24 mantissa bits where a pass would otherwise be matrix-bound).      */
     int32_t  reserved[5];
 } dlco_cfg;
 

@@ -59,6 +59,7 @@ struct dlco_ctx {
     const float *pd_cur = nullptr, *nd_cur = nullptr;    // distance vectors of the current step (see gather_dists)
     DevBuf<int32_t> rho, kappa, act_ids, seed_ids;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
+    DevBuf<char> pplane[3];          // split-bf16 planes of W for the fused many-row projection (kernels_project.hip)
     float *xdist = nullptr, *xgrad = nullptr;   // exchange buffers (own allocations unless bound by the caller)
     DevBuf<int> k_active;
     DevBuf<double> dscal;
@@ -197,8 +198,16 @@ void project_many(dlco_ctx *c, const int32_t *ids_dev, int row0, int n, const fl
 {
     if (n <= 0) return;
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
-    c->vproj.alloc((size_t)r * VCHUNK);
     const RowRef rr = rows_of(c, ids_dev, row0, n);
+    // fused project + square + column sum, the rows of D streamed once and no r x n buffer (W up to 384 rows: four
+    // passes of 96; taller W - the start-up transient - takes the GEMM path below)
+    if (r <= 384 && c->F % 64 == 0) {
+        for (auto &pl : c->pplane) pl.alloc(project_rows_plane_bytes(c->F));
+        if (project_rows_sqdist(Wd, c->F, r, c->dists, c->F, c->F, rr.a, rr.b, row0, n, out_dev, c->pplane[0].p, c->pplane[1].p,
+                                c->pplane[2].p, c->cfg.grad_bf16 != 0, c->stream))
+            return;
+    }
+    c->vproj.alloc((size_t)r * VCHUNK);
     for (int c0 = 0; c0 < n; c0 += VCHUNK) {
         const int nc = std::min(VCHUNK, n - c0);
         GemmArgs g;
@@ -218,6 +227,23 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
 {
     if (n <= 0) return;
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
+    if (c->cfg.grad_bf16 && r <= 96 && c->F % 64 == 0) {
+        // BASELINE configs[4] variant: the batch projection on the bf16 matrix cores too (operands rounded to bf16 once,
+        // fp32 accumulation), K split over enough slices to fill the chip, slices summed in order
+        const int blocks = (n + 127) / 128;
+        int ks = 1;
+        while (ks * 2 * blocks <= 256 && (c->F / 64) % (ks * 2) == 0) ks *= 2;
+        const size_t need = (size_t)ks * r * n;
+        if (need > c->proj_slab_floats) { c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+        for (auto &pl : c->pplane) pl.alloc(project_rows_plane_bytes(c->F));
+        const RowRef rr = rows_of(c, ids_dev, 0, n);
+        c->prof.begin(PROF_PROJECT);
+        const bool ok = project_rows_slab(Wd, c->F, r, c->dists, c->F, c->F, rr.a, rr.b, n, ks, c->proj_slab.p, n, c->pplane[0].p,
+                                          c->pplane[1].p, c->pplane[2].p, true, c->stream);
+        if (ok) sqdist_from_proj(c->proj_slab.p, ks, r, n, n, out_dev, c->stream);
+        c->prof.end(PROF_PROJECT);
+        if (ok) return;
+    }
     const int bm = r <= 64 ? 64 : 128, bn = n <= 64 ? 64 : 128;
     const long tiles = (long)((r + bm - 1) / bm) * ((n + bn - 1) / bn);
     long split = std::max(1L, std::min((512 + tiles - 1) / tiles, (long)c->F / 128));

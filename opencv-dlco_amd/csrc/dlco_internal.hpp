@@ -143,6 +143,16 @@ size_t bf16x2_slab_floats(int M, int N, int ksplit = 0);
 bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long ldg, int N, int K, float alpha, float *C,
                            long ldc, const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo,
                            float *slab, hipStream_t s, int ksplit = 0, void *plane_lo2 = nullptr, bool g_tiled = false);
+// P1 + P2 for many rows without the r x N projection (kernels_project.hip): dist[n] = |W x_n|^2, x_n = row ids[n] (or
+// row0 + n) of D, minus row ids2[n] in pair mode.  Three-way split-bf16 MFMA (fp32-level accuracy) or, with bf16 = true,
+// operands rounded to bf16 once (BASELINE configs[4]).  planes: workspaces of project_rows_plane_bytes(F) bytes each.
+size_t project_rows_plane_bytes(int K);
+bool project_rows_sqdist(const float *W, long ldw, int r, const float *D, long ldd, int F, const int32_t *ids, const int32_t *ids2,
+                         long row0, int nrows, float *dist, void *plane_hi, void *plane_lo, void *plane_lo2, bool bf16, hipStream_t s);
+// raw partial projections of a few rows, K split over ksplit slices: slab [ksplit][r][ldn] (r <= 96)
+bool project_rows_slab(const float *W, long ldw, int r, const float *D, long ldd, int F, const int32_t *ids, const int32_t *ids2,
+                       int nrows, int ksplit, float *slab, long ldn, void *plane_hi, void *plane_lo, void *plane_lo2, bool bf16,
+                       hipStream_t s);
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).

@@ -403,6 +403,16 @@ void launch_rows(const Bf2Dev &g, dim3 grid, hipStream_t s)
 
 }  // namespace
 
+// fragment-ordered bf16 planes of X [M][K] (M <= 160): hi, lo (and lo2 when given); see split_x_kernel
+void split_planes_bf16(const float *X, long ldx, int M, int K, void *hi, void *lo, void *lo2, hipStream_t s)
+{
+    const int mt = (M + 31) / 32;
+    const long total = (long)(K / 16) * mt * 64;
+    hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, K,
+                       static_cast<bf16x8 *>(hi), static_cast<bf16x8 *>(lo), static_cast<bf16x8 *>(lo2));
+    DLCO_HIP(hipGetLastError());
+}
+
 size_t bf16x2_plane_bytes(int M, int K) { return (size_t)((M + 31) / 32) * 32 * K * sizeof(__bf16); }
 size_t bf16x2_slab_floats(int M, int N, int ksplit) { return (size_t)(ksplit > 0 ? ksplit : KS) * M * N; }
 

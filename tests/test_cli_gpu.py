@@ -351,31 +351,88 @@ def test_full_pipeline_of_the_reference_tools(tmp_path):
         np.save(d / "Indices.npy", pairs)
         sets[name] = d
     run = lambda args: subprocess.run(args, capture_output=True, text=True, timeout=900)
-    # 1. pooling-region distances of the training set
+    from oracle import ref
+    tr_patches, tr_pairs = np.load(sets["train"] / "Patches.npy"), np.load(sets["train"] / "Indices.npy")
+    # 1. pooling-region distances of the training set == the oracle's restatement of comp-fulldists, pair by pair
     r = run([tool("comp-fulldists"), str(flt), str(sets["train"]), str(tmp_path / "fulldists")])
     assert r.returncode == 0 and "Bins: #8 Sigma: 1.4 bNorm: 1" in r.stdout, r.stderr
     full = np.load(tmp_path / "fulldists" / "Distance.npy")
+    flab = np.load(tmp_path / "fulldists" / "Label.npy").ravel()
     assert full.shape == (1200, regions) and (full >= 0).all()
-    # 2. pooling-region selection
+    sub = np.arange(0, 1200, 5)
+    want_full = np.stack([ref.full_dists(tr_patches[a], tr_patches[b], PR) for a, _, b, _ in tr_pairs[sub]])
+    assert np.abs(full[sub] - want_full).max() <= 1e-5 * want_full.max()           # cuda::gemm / reduce order unspecified there
+    assert np.array_equal(flab, (tr_pairs[:, 1] == tr_pairs[:, 3]).astype(np.uint8))
+    # 2. pooling-region selection: every row pr-learn saved is, bit for bit, the oracle's w of that iteration, and the
+    #    log's Loss / Regul / NNZ are the oracle's validation numbers for it (src/pr-learn.cpp:302-369)
     r = run([tool("pr-learn"), str(flt), str(tmp_path / "fulldists"), str(tmp_path / "prs"), "-mu", "0.001", "-gamma", "0.5", "-iters", "6000",
              "-logstep", "2000", "-maxdim", "100000"])
     assert r.returncode == 0 and "[saved]" in r.stdout, r.stdout + r.stderr
     w = np.load(tmp_path / "prs" / "w.npy")
     assert w.shape[1] == regions and (w[-1] > 0).any()
-    # 3. descriptors of the selected regions, both sets
+    prt = ref.PrTrainer(full, flab, mu=0.001, gamma=0.5)
+    lines = r.stdout.splitlines()
+    k = done = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(Best|Step): (\d+)  Loss: (\S+) Regul: (\S+) Obj: \S+ \(\S+\)  NNZ: (\d+) ", l)
+        if not m:
+            continue
+        t = int(m.group(2))
+        prt.steps(t + 1 - done)                                        # iterations 0..t have run when the line is printed
+        done = t + 1
+        lo, rg, nz = prt.validate()
+        assert abs(lo - float(m.group(3))) <= 1.5e-6 and abs(rg - float(m.group(4))) <= 1.5e-6 and nz == int(m.group(5)), l
+        if m.group(1) == "Best" and lines[i + 1].endswith("[saved]"):
+            assert np.array_equal(w[k], prt.state()["w"]), "saved row %d differs from the oracle's w at t = %d" % (k, t)
+            k += 1
+    assert k == len(w) >= 1
+    prt.close()
+    # 3. descriptors of the selected regions, both sets == the oracle's get_desc + pooling + clamp, differenced per pair
     for name in sets:
         r = run([tool("comp-uprjdists"), str(flt), str(sets[name]), "-prj", str(tmp_path / "prs"), "-id", str(len(w) - 1), "-out", str(tmp_path / (name + "-unproj"))])
         assert r.returncode == 0, r.stderr
     D = np.load(tmp_path / "train-unproj" / "Distance.npy")
+    Ltr = np.load(tmp_path / "train-unproj" / "Label.npy").ravel()
     assert D.shape[0] == 1200 and D.shape[1] % 8 == 0
-    # 4. the projection
+    sPR = ref.select_pr_filters(PR, w[-1])
+    assert D.shape[1] == 8 * len(sPR)
+    sub = np.arange(0, 1200, 7)
+    descs = {}
+    for a, _, b, _ in tr_pairs[sub]:
+        for pid in (a, b):
+            if pid not in descs:
+                descs[pid] = ref.patch_descriptor(tr_patches[pid], sPR)
+    want_D = np.stack([descs[a] - descs[b] for a, _, b, _ in tr_pairs[sub]])
+    assert np.abs(D[sub] - want_D).max() <= 6e-7                       # descriptors are <= 1: one float rounding of either side
+    assert np.array_equal(Ltr, (tr_pairs[:, 1] == tr_pairs[:, 3]).astype(np.uint8))
+    # 4. the projection: pj-learn's saved model against the oracle's free-running trainer on the same file (the hinge mask
+    #    makes trajectories chaotic: rank, objective and FPR@95 in the band the sample size allows), and its own consistency
     r = run([tool("pj-learn"), str(tmp_path / "train-unproj"), str(tmp_path / "model"), "-iters", "150", "-batch", "64", "-logstep", "50", "-mu", "0.002"])
     assert r.returncode == 0 and "[saved]" in r.stdout, r.stdout + r.stderr
-    # 5. cross-set evaluation
-    r = run([tool("eval-fpr95"), str(tmp_path / "model"), str(tmp_path / "test-unproj")])
-    assert r.returncode == 0, r.stderr
-    m = re.search(r"FPR95: (\d+\.\d+)", r.stdout)
-    assert m and 0.0 <= float(m.group(1)) <= 100.0
-    own = run([tool("eval-fpr95"), str(tmp_path / "model"), str(tmp_path / "train-unproj")])
-    assert own.returncode == 0
-    print("pipeline: FPR95 on the training set", re.search(r"FPR95: (\d+\.\d+)", own.stdout).group(1), "cross-set", m.group(1))
+    Wm, Am = np.load(tmp_path / "model" / "W.npy"), np.load(tmp_path / "model" / "A.npy")
+    assert relmax(Wm.T.astype(np.float64) @ Wm.astype(np.float64), Am) <= 1e-5
+    last = _last_entry(r.stdout)
+    otr = ref.Trainer(D, Ltr, B=64, mu=0.002, gamma=0.5, grad_order=1)
+    for _ in range(151):                                               # t = 0 .. 150
+        otr.step()
+    lo_o, rg_o = otr.validate()
+    dim_o, f95_o, auc_o = otr.stats()
+    assert last["t"] == 150 and abs(last["rank"] - dim_o) <= max(3, dim_o // 10), (last, dim_o)
+    assert abs(last["loss"] - lo_o) <= 0.15 * lo_o + 1e-3 and abs(last["regul"] - rg_o) <= 0.15 * rg_o + 1e-4, (last, lo_o, rg_o)
+    otr.close()
+    # 5. evaluation: eval-fpr95's line for the saved W is the oracle's ComputePJStats of that W, on the training set and
+    #    on the SECOND patch set (cross-set), over the distances the oracle itself computes
+    for name in ("train", "test"):
+        ev = run([tool("eval-fpr95"), str(tmp_path / "model"), str(tmp_path / (name + "-unproj"))])
+        assert ev.returncode == 0, ev.stderr
+        m = STAT.match(ev.stdout.strip())
+        assert m, ev.stdout
+        De = np.load(tmp_path / (name + "-unproj") / "Distance.npy")
+        Le = np.load(tmp_path / (name + "-unproj") / "Label.npy").ravel()
+        d_o = ref.project_sqdist(Wm, De)
+        f_o, a_o = ref.roc_stats(d_o, Le)
+        assert int(m.group(1)) == Wm.shape[0]
+        # FPR95 is printed in per cent with two decimals; ties in the ranking may move one row
+        assert abs(float(m.group(4)) - 100.0 * f_o) <= 0.006 + 100.0 / max(int((Le == 0).sum()), 1), (name, m.group(4), f_o)
+        assert abs(float(m.group(2)) - a_o) <= 1e-4, (name, m.group(2), a_o)
+        print("pipeline: %s set FPR95 %s %% (oracle %.2f %%), AUC %s (oracle %.6f)" % (name, m.group(4), 100 * f_o, m.group(2), a_o))

@@ -12,8 +12,18 @@ pytestmark = pytest.mark.gpu
 # fp32 tolerances (relative to the largest magnitude of the reference quantity)
 TOL_DIST = 2e-5      # per-pair squared distances: K = F fmaf chain vs OpenBLAS sgemm order
 TOL_GRAD = 5e-6      # dfAvg after one fused SYRK + dual average, vs fp64 accumulation
-TOL_A = 5e-4         # PSD-projected A: subspace tracker tolerance (eig_tol = 2e-4) + eigen sensitivity
+TOL_A = 1e-4         # PSD-projected A: SURVEY 8(d) gate (tracker eig_tol = 2e-4 on the weighted residual; measured ~1e-5)
 TOL_LOSS = 1e-5      # validation hinge loss
+
+_MEASURED = {}       # largest error seen per check, printed (pytest -s) and written out by the last test of this module
+
+
+def _check_A(tag, got, want):
+    """PSD-projected A against the oracle's ssyevr result, SURVEY 8(d): <= 1e-4 of the largest entry."""
+    e = relmax(got, want)
+    _MEASURED[tag] = max(_MEASURED.get(tag, 0.0), e)
+    assert e <= TOL_A, (tag, e)
+    return e
 
 
 @pytest.fixture(scope="module")
@@ -233,7 +243,7 @@ def test_psd_project(dlco, ref, F, rank_hint):
     ctx = dlco.Context(F, 16, B=4, mu=mu, gamma=gamma)
     W, A = ctx.psd_project(G, t)
     assert abs(W.shape[0] - Wref.shape[0]) <= 1          # eigenvalues within fp32 noise of mu may flip
-    assert relmax(A, Ap) <= TOL_A
+    _check_A("psd_project F=%d" % F, A, Ap)
     # rows ascending in eigenvalue (LAPACK order), mutually orthogonal
     n2 = (W.astype(np.float64) ** 2).sum(1)
     assert (np.diff(n2) >= -1e-6 * n2.max()).all()
@@ -266,7 +276,7 @@ def test_teacher_forced_steps_golden(dlco, ref, fname):
         assert np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap)
         if np.array_equal(rho, z["s%d_rho" % s]) and np.array_equal(kap, z["s%d_kappa" % s]):
             assert relmax(ctx.dfavg(), z["s%d_dfavg" % s]) <= TOL_GRAD * 4
-            assert relmax(ctx.A(), z["s%d_A" % s]) <= TOL_A
+            _check_A("teacher-forced golden " + fname, ctx.A(), z["s%d_A" % s])
     ctx.close()
 
 
@@ -294,7 +304,7 @@ def test_teacher_forced_live(dlco, ref):
         rho, kap = ref.viol_counts(pd, nd)
         if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
             assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
-            assert relmax(ctx.A(), after["A"]) <= TOL_A
+            _check_A("teacher-forced live F=128 B=200", ctx.A(), after["A"])
             checked += 1
     assert checked >= 20
     ctx.close()
@@ -474,7 +484,7 @@ def test_pair_mode_against_oracle(dlco, ref):
         rho, kap = ref.viol_counts(pd, nd)
         if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
             assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
-            assert relmax(ctx.A(), after["A"]) <= TOL_A
+            _check_A("teacher-forced pair mode", ctx.A(), after["A"])
             checked += 1
     assert checked >= 5
     ctx.close()
@@ -684,12 +694,25 @@ def test_tracker_block_above_1024_rows_and_the_batch_cap(dlco, ref):
     nz = int((np.abs(W).max(axis=1) > 0).sum())
     assert nz == r
     assert abs(r - after["r"]) <= 2
-    err_a = relmax(ctx.A(), after["A"])
+    err_a = _check_A("B=1100 first step F=2048", ctx.A(), after["A"])
     print("B=1100 first step: rank %d (oracle %d), err_A %.2e" % (r, after["r"], err_a))
-    assert err_a <= TOL_A
     assert ctx.counters()["nonconverged"] == 0
     ctx.close()
     tr.close()
     with pytest.raises(dlco.DlcoError) as e:
         dlco.Context(8192, N, B=2100)
     assert "4096" in str(e.value)
+
+
+def test_zz_report_measured_errors():
+    """Not a check: prints the largest A+ error each test above measured against its 1e-4 gate (and leaves the
+    numbers in gpurun_out/ when that directory exists, for profiles/)."""
+    import json
+    import os
+    line = json.dumps({"TOL_A": TOL_A, "max_err_A": _MEASURED}, sort_keys=True)
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_err_A.json"), "w") as f:
+            f.write(line + "\n")
+    assert all(v <= TOL_A for v in _MEASURED.values())
