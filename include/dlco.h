@@ -44,7 +44,10 @@ typedef struct dlco_cfg {
     int32_t  device;     /* HIP device ordinal                             (:267) */
     int32_t  rank;       /* data-parallel rank: owns batch slots [rank*B/world, (rank+1)*B/world) */
     int32_t  world;      /* number of ranks (1 = the reference's single device)           */
-    float    eig_tol;    /* subspace tracker tolerance on c*|residual| / max e (default 2e-4) */
+    float    eig_tol;    /* subspace tracker tolerance on the weighted c*|residual| / max e (default 2e-4; the first
+                          * update after a (re)start converges to a quarter of it).  Measured error of A+ against
+                          * ssyevr at the default: 1.5e-5 (rank 64) / 3.6e-5 (rank 128) of its largest entry at
+                          * F = 8192, i.e. inside SURVEY 8(d)'s 1e-4 gate; 5e-5 costs 6 % / 40 % of the step rate */
     int32_t  eig_guard;  /* guard vectors kept beyond the positive eigenspace (default 32)  */
     int32_t  eig_max_iter; /* filter+Rayleigh-Ritz iterations per step before giving up      */
                           /* The tracker block holds at most min(F, max(1024, 2*B + 2*eig_guard)) rows (positive
@@ -138,7 +141,9 @@ int dlco_step_finish(dlco_ctx *ctx);
 #define DLCO_BUF_DIST   1   /* f32 [world][2*B/world]: rank g's slice holds the distances of its
                                B/world positive slots, then of its B/world negative slots   */
 #define DLCO_BUF_GRAD   2   /* f32 [F*F]: this rank's dLoss partial                    */
-#define DLCO_BUF_DFAVG  3   /* f32 [F*F]: running dual average                         */
+#define DLCO_BUF_DFAVG  3   /* f32 [F*F]: running dual average.  A single-rank context at F = 8192 keeps only the tiles on
+                               or above the diagonal: 2080 contiguous row-major 128 x 128 blocks, tile (I, J), I <= J, at
+                               block index 64 I - I (I - 1) / 2 + J - I (dlco_get_dfavg / dlco_set_state convert)      */
 #define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
 #define DLCO_BUF_GATHER 5   /* f32 [world][rows*F/world]: column slabs of a tracker product
                                (sharded contexts only)                                   */
@@ -219,8 +224,9 @@ int dlco_project_sqdist(dlco_ctx *ctx, const int32_t *row_ids_host, int32_t n,
 /* V1: rho_i = #{j : pd_i + 1 > nd_j}, kappa_j = #{i : pd_i + 1 > nd_j}. */
 int dlco_viol_counts(dlco_ctx *ctx, const float *pd_host, const float *nd_host, int32_t B,
                      int32_t *rho_host, int32_t *kappa_host);
-/* Q1+U1: dfavg_out = alpha*dfavg_in + beta*(P^T diag(rho) P - N^T diag(kappa) N) with rows
- * taken from the resident Distance matrix (fused SYRK + dual average). */
+/* Q1+U1: dfavg_out = beta*dfavg_in + alpha*(P^T diag(rho) P - N^T diag(kappa) N) with rows
+ * taken from the resident Distance matrix (fused SYRK + dual average; the step uses alpha = 1/(B*B*(t+1)),
+ * beta = t/(t+1), src/pj-learn.cpp:422). */
 int dlco_grad_rda(dlco_ctx *ctx, const int32_t *pos_rows_host, const int32_t *neg_rows_host,
                   const int32_t *rho_host, const int32_t *kappa_host, int32_t B,
                   float alpha, float beta, const float *dfavg_in_host, float *dfavg_out_host);
@@ -232,7 +238,9 @@ int dlco_psd_project(dlco_ctx *ctx, const float *dfavg_host, uint32_t t,
  * out[rows,F] = X[rows,F] * G[F,F] for a symmetric G, rows <= 128.  mode 0 = fp32 MFMA (k-ordered
  * fmaf chain), mode 1 = two-way split-bf16 MFMA with fp32 accumulation (the Chebyshev filter;
  * relative error ~1e-5), mode 2 = three-way split-bf16 MFMA (the Rayleigh-Ritz product when
- * F % 512 == 0; error at the level of fp32 rounding, ~1e-7). */
+ * F % 512 == 0; error at the level of fp32 rounding, ~1e-7).  Modes 3 / 4 (F == 8192 only) are modes 1 / 2 on the packed
+ * upper-tile form of G that a single-rank trainer keeps its dual average in: only the upper triangle of G_host is read,
+ * and every 128 x 128 tile is fetched from HBM once per product.  rows <= 160 for modes 1 / 3. */
 int dlco_sym_product(dlco_ctx *ctx, const float *X_host, int32_t rows, const float *G_host, int32_t mode,
                      float *out_host);
 /* H1: sum_i sum_j max(pos_i + 1 - neg_j, 0)  (src/kernelop-opencv.cu:49-80). */

@@ -46,6 +46,7 @@ struct dlco_ctx {
     int r = 0;                       // rows of W (0 = the reference's all-zero F x F W)
     double traceA = 0.0;
     DevBuf<float> dfavg, grad, W;
+    bool packed = false;             // dfavg holds the packed upper tiles (syrk_packed_floats(F) floats), not the F x F matrix
     int w_cap = 0;
     std::vector<int32_t> h_pos_rows, h_neg_rows;
     int32_t *pin_ids = nullptr;      // pinned staging of the sampled row ids: [2 slots][2B], no sync after the upload
@@ -265,7 +266,7 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
 
 // dst = beta*dst_in + alpha * X^T diag(w) X over the active rows (upper triangle computed, mirrored)
 void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev, int kmax, float alpha, float beta,
-               float *dst)
+               float *dst, bool packed = false)
 {
     const int kpad = (kmax + 31) & ~31;                 // the lists are zero padded up to here
     const RowRef rr = rows_of(c, ids, 0, kpad);
@@ -274,11 +275,12 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
         (!c->shard || (c->comm.c0 % 128 == 0 && c->comm.cw % 128 == 0))) {
         c->prof.begin(PROF_GRAD_SYRK);
         const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream,
-                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0);
+                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0, packed);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;
     }
+    DLCO_CHECK(!packed, DLCO_ERR_INVALID, "grad_syrk: the packed layout needs the fused kernel");
     GemmArgs g;
     g.M = c->F; g.N = c->F; g.K = kmax;
     g.A.p = c->dists; g.A.ld = c->F; g.A.kmajor = true; g.A.row_ids = rr.a; g.A.row_ids2 = rr.b; g.A.row_scale = w;
@@ -352,7 +354,7 @@ void step_grad(dlco_ctx *c)
                       c->act_w.p, c->k_active.p, c->stream);
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
-    if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p);
+    if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed);
     else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->xgrad);
     c->phase = 2;
 }
@@ -505,6 +507,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c = new dlco_ctx();
         c->cfg = *cfg;
         if (c->cfg.eig_tol <= 0.f) c->cfg.eig_tol = 2e-4f;
+        if (const char *e = std::getenv("DLCO_EIG_TOL")) { const float v = (float)std::atof(e); if (v > 0.f) c->cfg.eig_tol = v; }   // developer override
         if (c->cfg.eig_guard <= 0) c->cfg.eig_guard = 32;
         if (c->cfg.eig_max_iter <= 0) c->cfg.eig_max_iter = 40;
         DLCO_HIP(hipGetDeviceProperties(&c->prop, cfg->device));
@@ -516,7 +519,10 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         DLCO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->prof.s = c->stream;
         const size_t FF = (size_t)c->F * c->F;
-        c->dfavg.alloc(FF); c->dfavg.zero(c->stream);
+        // One rank, whole dual average, F = 8192: dfAvg is kept as its packed upper 128 x 128 tiles (136 MB instead of
+        // 268 MB) - the SYRK stores no mirror and the tracker's products fetch every tile once (kernels_bf16x2.hip).
+        c->packed = cfg->world == 1 && cfg->shard == 0 && EigTracker::packed_supported(c->F);
+        c->dfavg.alloc(c->packed ? syrk_packed_floats(c->F) : FF); c->dfavg.zero(c->stream);
         c->grad.alloc(FF);
         // block capacity (positive rank + guards).  At t = 0 (W = 0, every pair violates) the positive
         // eigenspace of -dfAvg has up to B dimensions (the negative rows), so the capacity follows the
@@ -528,6 +534,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
                    "global batch too large for the eigen tracker: 2*B + 2*eig_guard must not exceed 4096 when F > 4096");
         c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
         c->eig->set_profiler(&c->prof);
+        c->eig->set_packed(c->packed);
         c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
         c->W.alloc((size_t)c->w_cap * c->F);
         const int B = c->B;
@@ -743,7 +750,8 @@ int dlco_dev_buffer(dlco_ctx *c, int32_t which, void **dev_ptr, size_t *bytes)
     switch (which) {
     case DLCO_BUF_DIST: *dev_ptr = c->xdist; *bytes = (size_t)2 * c->B * sizeof(float); return DLCO_OK;
     case DLCO_BUF_GRAD: *dev_ptr = c->xgrad; *bytes = FF; return DLCO_OK;
-    case DLCO_BUF_DFAVG: *dev_ptr = c->dfavg.p; *bytes = FF; return DLCO_OK;
+    case DLCO_BUF_DFAVG:                                          // (packed contexts: the packed upper tiles, see dlco.h)
+        *dev_ptr = c->dfavg.p; *bytes = c->packed ? syrk_packed_floats(c->F) * sizeof(float) : FF; return DLCO_OK;
     case DLCO_BUF_W: *dev_ptr = c->W.p; *bytes = (size_t)c->r * c->F * sizeof(float); return DLCO_OK;
     case DLCO_BUF_DATA:
         if (!c->have_data) return DLCO_ERR_INVALID;
@@ -876,7 +884,15 @@ int dlco_get_A(dlco_ctx *c, float *A_host)
 int dlco_get_dfavg(dlco_ctx *c, float *out)
 {
     if (!c || !out) return DLCO_ERR_INVALID;
-    return guarded(c, [&] { d2h(c, out, c->dfavg.p, (size_t)c->F * c->F * sizeof(float)); });
+    return guarded(c, [&] {
+        if (c->packed) {                                         // unpack into the F x F scratch first
+            DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_dfavg: step in flight");
+            syrk_unpack_upper(c->dfavg.p, c->F, c->grad.p, c->F, c->stream);
+            d2h(c, out, c->grad.p, (size_t)c->F * c->F * sizeof(float));
+            return;
+        }
+        d2h(c, out, c->dfavg.p, (size_t)c->F * c->F * sizeof(float));
+    });
 }
 
 int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float *W_host, int32_t r)
@@ -886,7 +902,11 @@ int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_set_state: step in flight");
         DLCO_CHECK(r >= 0 && r <= c->w_cap, DLCO_ERR_INVALID, "dlco_set_state: r out of range");
         c->t = t;
-        if (dfavg_host) {
+        if (dfavg_host && c->packed) {                            // the upper tiles are all that is kept
+            h2d(c, c->grad.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+            syrk_mirror_upper(c->grad.p, c->F, c->F, c->stream);   // (diagonal tiles are stored whole: make them exactly symmetric)
+            syrk_pack_upper(c->grad.p, c->F, c->F, c->dfavg.p, c->stream);
+        } else if (dfavg_host) {
             h2d(c, c->dfavg.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
             if (!c->shard) syrk_mirror_upper(c->dfavg.p, c->F, c->F, c->stream);
         }
@@ -994,6 +1014,15 @@ int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_
             if (!c->shard) syrk_mirror_upper(c->grad.p, c->F, c->F, c->stream);
         } else fill_f32(c->grad.p, 0.f, FF, c->stream);
         build_active_rows(pr.p, nr.p, rho.p, kap.p, B, 0, B, ids.p, w.p, k.p, c->stream);
+        if (c->packed) {                                         // the trainer's own kernel and layout: pack, update, unpack
+            DevBuf<float> pk;
+            pk.alloc(syrk_packed_floats(c->F));
+            syrk_pack_upper(c->grad.p, c->F, c->F, pk.p, c->stream);
+            grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, pk.p, true);
+            syrk_unpack_upper(pk.p, c->F, c->grad.p, c->F, c->stream);
+            d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));
+            return;
+        }
         grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, c->grad.p);
         d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));
     });
@@ -1006,16 +1035,21 @@ int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_
         DLCO_HIP(hipSetDevice(c->cfg.device));
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_psd_project: step in flight");
         const size_t FF = (size_t)c->F * c->F;
-        DevBuf<float> G;
+        DevBuf<float> G, Gp;
         G.alloc(FF);
         h2d(c, G.p, dfavg_host, FF * sizeof(float));
+        if (c->packed) {                                         // the tracker of a packed context reads packed tiles
+            Gp.alloc(syrk_packed_floats(c->F));
+            syrk_mirror_upper(G.p, c->F, c->F, c->stream);
+            syrk_pack_upper(G.p, c->F, c->F, Gp.p, c->stream);
+        }
         c->eig->reset();
         const float cscale = (float)(std::sqrt((double)t + 1.0) / (double)c->cfg.gamma);
         double tr = 0.0;
         bool conv = true;
         DevBuf<float> Wd;
         Wd.alloc((size_t)c->w_cap * c->F);
-        const int rr = c->eig->update(G.p, c->cfg.mu, cscale, Wd.p, &tr, &conv);
+        const int rr = c->eig->update(c->packed ? Gp.p : G.p, c->cfg.mu, cscale, Wd.p, &tr, &conv);
         c->eig->reset();
         if (rr > 0) {
             if (W_host) d2h(c, W_host, Wd.p, (size_t)rr * c->F * sizeof(float));
@@ -1034,7 +1068,7 @@ int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_
 
 int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float *G_host, int32_t mode, float *out_host)
 {
-    if (!c || !X_host || !G_host || !out_host || rows < 1 || rows > 128) return DLCO_ERR_INVALID;
+    if (!c || !X_host || !G_host || !out_host || rows < 1 || rows > ((mode == 1 || mode == 3) ? 160 : 128)) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         const int F = c->F, pad = ((rows + 31) / 32) * 32;
@@ -1044,7 +1078,19 @@ int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float
         h2d(c, X.p, X_host, (size_t)rows * F * sizeof(float));
         h2d(c, G.p, G_host, (size_t)F * F * sizeof(float));
         bool ok;
-        if (mode == 1 || mode == 2) {
+        if (mode == 3 || mode == 4) {                            // packed upper tiles, every tile fetched once
+            DevBuf<char> hi, lo, lo2;
+            hi.alloc(bf16x2_plane_bytes(rows, F)); lo.alloc(bf16x2_plane_bytes(rows, F));
+            if (mode == 4) lo2.alloc(bf16x2_plane_bytes(rows, F));
+            DevBuf<float> slab, Gp;
+            slab.alloc((size_t)4 * pad * F);
+            Gp.alloc(syrk_packed_floats(F));
+            syrk_mirror_upper(G.p, F, F, c->stream);              // diagonal tiles are stored whole: take their lower half from the upper
+            syrk_pack_upper(G.p, F, F, Gp.p, c->stream);
+            ok = skinny_product_sym(X.p, F, rows, Gp.p, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, hi.p, lo.p, slab.p, c->stream,
+                                    mode == 4 ? lo2.p : nullptr);
+            sync(c);
+        } else if (mode == 1 || mode == 2) {
             DevBuf<char> hi, lo, lo2;
             hi.alloc(bf16x2_plane_bytes(rows, F)); lo.alloc(bf16x2_plane_bytes(rows, F));
             if (mode == 2) lo2.alloc(bf16x2_plane_bytes(rows, F));

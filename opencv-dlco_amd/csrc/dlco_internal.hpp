@@ -162,9 +162,20 @@ bool project_rows_slab(const float *W, long ldw, int r, const float *D, long ldd
 // lower triangle := upper triangle: the fused SYRK relies on an exactly symmetric dual average (it keeps
 // it so itself); a matrix that comes from outside (dlco_set_state, dlco_grad_rda) is symmetrised first
 void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s);
+// packed = true: C holds the packed upper tiles (syrk_packed_floats(F) floats, ldc ignored): tile (bi, bj), bi <= bj, is a
+// contiguous row-major 128 x 128 block at tile index bi*nt - bi*(bi-1)/2 + (bj - bi); no mirrored store.
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
-                  int slab_cols = 0, bool bf16 = false);
+                  int slab_cols = 0, bool bf16 = false, bool packed = false);
+size_t syrk_packed_floats(int F);
+void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s);      // upper tiles of a full matrix -> packed
+void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s);    // packed -> full symmetric matrix
+// out[M][F] = alpha * X[M][F] * G + b1*E1 + b2*E2 for a symmetric G given as its packed upper tiles, every tile fetched
+// from HBM once (kernels_bf16x2.hip, skinny_sym_kernel).  F == 8192 only (64 x 64 tiles on 8 XCDs x 32 CUs); M <= 160
+// (two-way split) / 96 (three-way, plane_lo2 != nullptr).  slab: >= 4*M*F floats.  Returns false for other shapes.
+bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, int F, float alpha, float *C, long ldc,
+                        const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo, float *slab,
+                        hipStream_t s, void *plane_lo2 = nullptr);
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,

@@ -11,6 +11,7 @@
 // positive eigenspace does; when it reaches F the method is the dense eigensolver.
 #pragma once
 
+#include <cstdlib>
 #include "dlco_internal.hpp"
 
 #include <initializer_list>
@@ -42,6 +43,11 @@ public:
     // G is sharded by columns over the ranks: every product with G computes the rank's column slab
     // and all-gathers the rest; everything else of the tracker is replicated (and deterministic).
     void set_shard(const ShardComm *sc) { shard_ = sc; }
+    // Every G handed to update() is the PACKED upper-tile form (syrk_packed_floats(F) floats, kernels_syrk.hip): the
+    // products take the symmetric kernel that fetches each tile once.  Only valid where packed_supported() holds.
+    void set_packed(bool on) { packed_ = on; }
+    bool packed() const { return packed_; }
+    static bool packed_supported(int F) { return F == 8192 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }
     const EigStats &stats() const { return st_; }
     float last_crit() const { return last_crit_; }
 
@@ -61,6 +67,8 @@ private:
 
     int F_, cap_, guard_, max_iter_;
     float tol_;
+    bool packed_ = false;
+    bool cold_ = true;               // no update since construction / reset(): the next one converges to tol_ / 4
     hipStream_t s_;
     int m_ = 0;                      // rows currently in the block
     bool have_theta_ = false;

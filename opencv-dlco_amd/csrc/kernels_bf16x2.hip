@@ -388,6 +388,222 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
     }
 }
 
+// ---- symmetric G stored as its packed upper tiles: every tile leaves HBM once ------------------------------------------
+// out[:, I] = sum_J X[:, J] G[J][I] over tile blocks; G[J][I] is the stored tile (I, J) read along its rows when I <= J
+// ("direct", exactly the chunk of skinny_rows_kernel), or the stored tile (J, I) read along its COLUMNS when J < I
+// ("transposed").  Every off-diagonal tile therefore has two users, output blocks I and J, and the Infinity Cache does
+// not help (tools/mall_probe.cpp: a table that fits it streams at the HBM rate all the same) - the second read has to
+// hit the XCD's own L2.  So the two users of a tile are put on the SAME XCD at the SAME time:
+//   * the 64 tile rows are the vectors of Z_2^6; block I meets block I ^ d, d = 0..63.  The 64 differences are dealt to
+//     four groups p by their two top bits h_p (01, 10, 11, 00); within group p the blocks are halved by a linear form
+//     f_p that vanishes on the group's differences (bit 5, bit 4, bit 5 ^ bit 4, bit 5), so that I and I ^ d always
+//     fall into the same half.  XCD x = 2 p + c takes the 32 blocks with f_p(I) = c, one workgroup each (one per CU),
+//     and in step s = 0..15 workgroup I works on the tile it shares with I ^ (16 h_p + s): the partner workgroup is on
+//     the same XCD and works on the same tile in the same step.  An XCD streams 16 tiles (1 MB) per step, each read
+//     twice back to back, and touches the X planes of its own 32 blocks only (1.5 MB, re-read every step: L2-resident).
+//   * every output block appears once per group: four partial slabs, summed in order by splitk_reduce_f32 - the same
+//     reduction as before; a column's K order is fixed by the schedule.  Deterministic.
+// Workgroups are dealt to XCDs round-robin by the hardware (block b -> XCD b % 8; observed, not guaranteed): a wrong guess
+// costs the L2 hits (the kernel then moves the full 268 MB again), never correctness.
+// Roles, LDS images, MFMA schedule and epilogue are those of skinny_rows_kernel; a transposed chunk is staged as
+// [64 k][128 columns] (row stride 132) and its B fragments are eight 4-byte reads of 32 consecutive columns.
+constexpr int SYM_TS = 132;                // LDS row stride of a transposed chunk image (floats)
+static_assert(RK_KC * SYM_TS * 4 <= RK_GBYTES, "a transposed chunk image must fit the G image");
+
+struct SymDev {
+    int M, K;
+    const bf16x8 *xhi, *xlo, *xlo2;
+    const float *G;               // packed upper tiles: tile (I, J), I <= J, at (I*nt - I*(I-1)/2 + J - I) * 16384 floats
+    float *slab;                  // [4][M][K] raw partial sums
+};
+
+template <int MT, int NS>
+__global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    constexpr int ABYTES = rk_abytes(MT, NS);
+    constexpr int APLANE = MT * 256;
+    constexpr int AENT = NS * APLANE;
+    constexpr int NA = (AENT + 255) / 256;
+    constexpr int NT = 64;                                     // tile rows (K = 8192)
+    float *gb0 = reinterpret_cast<float *>(lds_raw), *gb1 = reinterpret_cast<float *>(lds_raw + RK_GBYTES);
+    bf16x8 *ab0 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES), *ab1 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES + ABYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup -> (group p, half c, block I): see above
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int p = xcd >> 1, c = xcd & 1;
+    int I;
+    if (p == 0 || p == 3) I = (c << 5) | slot;
+    else {
+        const int b5 = slot >> 4, b4 = p == 1 ? c : (b5 ^ c);
+        I = (b5 << 5) | (b4 << 4) | (slot & 15);
+    }
+    const int dbase = (p == 0 ? 1 : (p == 1 ? 2 : (p == 2 ? 3 : 0))) << 4;
+    constexpr int nchunks = 32;                                // 16 tiles x 2 halves of 64 k
+    // chunk cc: partner block, orientation, byte offset of the stored tile
+    auto partner = [&](int cc) { return I ^ (dbase | (cc >> 1)); };
+    auto tile_bytes = [&](int J) {
+        const int a = min(I, J), b = max(I, J);
+        return (a * NT - a * (a - 1) / 2 + (b - a)) * (128 * 128 * (int)sizeof(float));
+    };
+
+    if (wave >= 8) {
+        // ---- loader -----------------------------------------------------------------------------------------
+        const int lt = tid - 512;
+        // direct chunk: thread -> 16-byte column gc4 of tile rows grow + 16 u; transposed: column c4 of tile rows half*64 + kr + 8 u
+        const int voff_d = ((lt >> 4) * 128 + 4 * (lt & 15)) * (int)sizeof(float);
+        const int voff_t = ((lt >> 5) * 128 + 4 * (lt & 31)) * (int)sizeof(float);
+        const int loff_d = (lt >> 4) * RK_RS + 4 * (lt & 15), loff_t = (lt >> 5) * SYM_TS + 4 * (lt & 31);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.G), 0, (NT * (NT + 1) / 2) * 128 * 128 * (int)sizeof(float), 0x00020000);
+        const int plane_bytes = MT * 32 * g.K * 2;
+        const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(g.xhi), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(g.xlo), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_lo2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(NS == 3 ? g.xlo2 : g.xlo), 0, plane_bytes, 0x00020000);
+        struct Stage { f32x4 gq[8]; bf16x8 aq[NA]; };
+        Stage s0, s1;
+        auto gload = [&](int cc, Stage &st) {
+            const int J = partner(cc), half = cc & 1;
+            const bool direct = I <= J;
+            const int voff = direct ? voff_d : voff_t;
+            const int soff = tile_bytes(J) + (direct ? half * 64 : half * 64 * 128) * (int)sizeof(float);
+            const int ustep = (direct ? 16 : 8) * 128 * (int)sizeof(float);
+#pragma unroll
+            for (int u = 0; u < 8; u++) st.gq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + u * ustep, 0));
+            const int a0 = (J * 8 + half * 4) * MT * 64 * 16;  // the X planes' slice for block J, this half: byte offset inside a plane
+#pragma unroll
+            for (int v = 0; v < NA; v++) {
+                const __amdgpu_buffer_rsrc_t &ra = (v / MT == 0) ? rs_hi : ((v / MT == 1) ? rs_lo : rs_lo2);
+                st.aq[v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, 16 * lt, a0 + (v % MT) * 256 * 16, 0));
+            }
+        };
+        auto gstore = [&](int cc, const Stage &st) {                 // into image cc & 1
+            float *gb = (cc & 1) ? gb1 : gb0;
+            bf16x8 *ab = (cc & 1) ? ab1 : ab0;
+            const bool direct = I <= partner(cc);
+            const int loff = direct ? loff_d : loff_t, lstep = direct ? 16 * RK_RS : 8 * SYM_TS;
+#pragma unroll
+            for (int u = 0; u < 8; u++) *reinterpret_cast<f32x4 *>(gb + loff + u * lstep) = st.gq[u];
+#pragma unroll
+            for (int v = 0; v < NA; v++) ab[lt + 256 * v] = st.aq[v];
+        };
+        // chunk q: multiplied in iteration q, copied to image q & 1 at the start of iteration q - 1, requested at iteration
+        // q - 3 into register set q & 1 (chunks 0..2 before the loop); no branch around a load in the steady state
+        gload(0, s0);
+        gload(1, s1);
+        gstore(0, s0);
+        gload(2, s0);
+        __syncthreads();
+        int cc = 0;
+        for (; cc + 4 < nchunks; cc += 2) {
+            gstore(cc + 1, s1); gload(cc + 3, s1); __syncthreads();
+            gstore(cc + 2, s0); gload(cc + 4, s0); __syncthreads();
+        }
+        // cc = 28: chunks 29, 30 wait in s1, s0; chunk 31 is still to be requested
+        gstore(29, s1); gload(31, s1); __syncthreads();            // iteration 28
+        gstore(30, s0); __syncthreads();                           // iteration 29
+        gstore(31, s1); __syncthreads();                           // iteration 30
+        __syncthreads();                                           // iteration 31
+        __syncthreads();                                           // the compute waves' K-half exchange
+        return;
+    }
+
+    // ---- compute: wave = (32-column tile of block I, half of the chunk's four K steps), operands from LDS only ------
+    const int lc = lane & 31, lh = lane >> 5;
+    const int nt = wave & 3, kh = wave >> 2;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+
+    struct Frag { f32x4 g0, g1; bf16x8 a[NS][MT]; };
+    auto fetch = [&](const float *gb, const bf16x8 *ab, bool direct, int q, Frag &f) {
+        if (direct) {
+            const float *pp = gb + (nt * 32 + lc) * RK_RS + 16 * q + 8 * lh;
+            f.g0 = *reinterpret_cast<const f32x4 *>(pp);
+            f.g1 = *reinterpret_cast<const f32x4 *>(pp + 4);
+        } else {
+            const float *pp = gb + (16 * q + 8 * lh) * SYM_TS + nt * 32 + lc;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { f.g0[j] = pp[j * SYM_TS]; f.g1[j] = pp[(4 + j) * SYM_TS]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) f.a[n][t] = ab[n * APLANE + (q * MT + t) * 64 + lane];
+    };
+    auto multiply = [&](const Frag &f) {
+        bf16x8 bh, bl, bl2;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float v = j < 4 ? f.g0[j & 3] : f.g1[j & 3];
+            bh[j] = (__bf16)v;
+            const float r1 = v - (float)bh[j];
+            bl[j] = (__bf16)r1;
+            if (NS == 3) bl2[j] = (__bf16)(r1 - (float)bl[j]);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            if (NS == 3) {                                   // smallest terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bl2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[NS - 1][t], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][t], bl, acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1][t], bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bh, acc[t], 0, 0, 0);
+        }
+    };
+    Frag fa;
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; cc++) {
+        const float *gb = (cc & 1) ? gb1 : gb0;
+        const bf16x8 *ab = (cc & 1) ? ab1 : ab0;
+        const bool direct = I <= partner(cc);
+        fetch(gb, ab, direct, 2 * kh, fa);
+        multiply(fa);
+        fetch(gb, ab, direct, 2 * kh + 1, fa);
+        multiply(fa);
+        __syncthreads();
+    }
+
+    // ---- the two K halves of a column tile meet in LDS; the raw group sum goes to its slab ---------------------------
+    float *red = reinterpret_cast<float *>(lds_raw);
+    if (kh == 1) {
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[((nt * MT + a) * 16 + r) * 64 + lane] = acc[a][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float *slab = g.slab + (long)p * g.M * g.K;
+        const int col = I * 128 + nt * 32 + lc;
+#pragma unroll
+        for (int a = 0; a < MT; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float sum = acc[a][r] + red[((nt * MT + a) * 16 + r) * 64 + lane];
+                const int i = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < g.M) slab[(long)i * g.K + col] = sum;
+            }
+    }
+}
+
+template <int MT, int NS>
+void launch_sym(const SymDev &g, hipStream_t s)
+{
+    const size_t lds = rk_lds_bytes(MT, NS);
+    static bool attr = false;
+    if (!attr) {
+        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((skinny_sym_kernel<MT, NS>), dim3(256), dim3(RK_T), lds, s, g);
+}
+
 template <int MT, int NS>
 void launch_rows(const Bf2Dev &g, dim3 grid, hipStream_t s)
 {
@@ -471,6 +687,37 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
     }
     DLCO_HIP(hipGetLastError());
     splitk_reduce_f32(slab, ks, M, N, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
+    return true;
+}
+
+// The same product for a symmetric G given as its packed upper tiles (see skinny_sym_kernel).
+bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, int F, float alpha, float *C, long ldc,
+                        const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo, float *slab,
+                        hipStream_t s, void *plane_lo2)
+{
+    const int mt = (M + 31) / 32;
+    if (F != 8192 || M < 1 || mt > 5 || (mt >= 4 && plane_lo2)) return false;
+    if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || (reinterpret_cast<uintptr_t>(Gpacked) & 15) != 0) return false;
+    const long total = (long)(F / 16) * mt * 64;
+    hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, F,
+                       static_cast<bf16x8 *>(plane_hi), static_cast<bf16x8 *>(plane_lo), static_cast<bf16x8 *>(plane_lo2));
+    SymDev g;
+    g.M = M; g.K = F;
+    g.xhi = static_cast<const bf16x8 *>(plane_hi); g.xlo = static_cast<const bf16x8 *>(plane_lo); g.xlo2 = static_cast<const bf16x8 *>(plane_lo2);
+    g.G = Gpacked; g.slab = slab;
+    if (plane_lo2) {
+        if (mt == 1) launch_sym<1, 3>(g, s);
+        else if (mt == 2) launch_sym<2, 3>(g, s);
+        else launch_sym<3, 3>(g, s);
+    } else {
+        if (mt == 1) launch_sym<1, 2>(g, s);
+        else if (mt == 2) launch_sym<2, 2>(g, s);
+        else if (mt == 3) launch_sym<3, 2>(g, s);
+        else if (mt == 4) launch_sym<4, 2>(g, s);
+        else launch_sym<5, 2>(g, s);
+    }
+    DLCO_HIP(hipGetLastError());
+    splitk_reduce_f32(slab, 4, M, F, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
     return true;
 }
 

@@ -690,6 +690,197 @@ __global__ __launch_bounds__(1024) void jacobi_seat8_kernel(const float *T, long
     }
 }
 
+// ---- n <= 160: blocks of eight columns, one WAVE per pair of blocks ------------------------------------------------
+// The seat kernels above spend a workgroup barrier and a full instruction stream on every one of the n - 1 rounds of a
+// sweep, and the round is bound by vector-instruction issue (12 - 16 waves on four SIMDs).  Here the tournament is
+// played between BLOCKS of eight columns: a wave takes two blocks and rotates all 64 cross pairs without leaving its
+// own part of the matrix - eight lanes per pair, the eight columns of block A stay in registers for the whole
+// meeting, the columns of block B pass through them from LDS in eight inner rounds (pair (A_g, B_(g+k) mod 8) in round
+// k) - so a sweep has nb - 1 barriers (nb = n / 8 blocks) instead of n - 1, and the LDS traffic of a rotation is one
+// column in and out instead of two.  The 28 pairs inside each block are rotated once per sweep (seven wave-private
+// rounds through LDS) before the blocks start to meet.  Blocks are paired by the circle method, computed from the
+// round number: columns never move in LDS, a single image suffices (160 columns: 100 KB).  Same rotation arithmetic,
+// tracked squared norms (refreshed exactly every sweep) and stopping rule as the kernels above.
+// Column j lives at G + j * 32 E; lane l of a pair's eight owns the 16-byte chunks l + 8 e (e < E).  E is odd, so
+// consecutive columns start 32 banks apart and the eight-column reads of a wave are conflict-free.
+constexpr int JBLK_MAX_N = 160;
+inline int jblk_chunks(int n) { return n <= 32 ? 1 : (n <= 96 ? 3 : 5); }
+inline int jblk_waves(int n) { const int nb = (n + 7) / 8; return (nb + (nb & 1)) / 2; }
+inline size_t jblk_lds_bytes(int n) { const int ncol = 16 * jblk_waves(n); return ((size_t)ncol * 32 * jblk_chunks(n) + ncol + 32) * sizeof(float); }
+
+template <int E>
+__global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
+                                                         float *scratch, int *sweeps_out, float stop_cos, float lam_cut)
+{
+    constexpr int LDC = 32 * E;
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;               // nw = block pairs = (number of blocks, made even) / 2
+    const int nbe = 2 * nw, ncol = 8 * nbe, m = nbe - 1;
+    float *G = sh, *nrm = sh + (size_t)ncol * LDC, *red = nrm + ncol;
+
+    // ---- shift: sigma = 1.01 * max_i sum_j |T_ij| + tiny  (Gershgorin) ------------------------
+    float rmax = 0.f;
+    for (int i = wave; i < n; i += nw) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += fabsf(T[(long)i * ldt + j]);
+        s = wsum(s);
+        rmax = fmaxf(rmax, s);
+    }
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    float sigma = 0.f;
+    for (int w = 0; w < nw; w++) sigma = fmaxf(sigma, red[w]);
+    sigma = 1.01f * sigma + 1e-30f;
+    const float cut2 = lam_cut + sigma > 0.f ? (lam_cut + sigma) * (lam_cut + sigma) : 0.f;
+    // ---- column j of G = sym(T) + sigma I; columns n .. ncol-1 and rows n .. LDC-1 are zero (a zero column is never rotated)
+    for (int e = tid; e < ncol * LDC; e += nthr) {
+        const int j = e / LDC, i = e % LDC;
+        float v = 0.f;
+        if (i < n && j < n) v = 0.5f * (T[(long)i * ldt + j] + T[(long)j * ldt + i]) + (i == j ? sigma : 0.f);
+        G[e] = v;
+    }
+    __syncthreads();
+
+    const float tol = 3e-6f;
+    const int g = lane >> 3, l = lane & 7;
+    float off_max = 0.f;
+    // one rotation of the pair (x: squared norm a, y: squared norm b); returns t * (x . y) for the tracked norms
+    auto rotate = [&](f32x4 (&x)[E], f32x4 (&y)[E], float a, float b) -> float {
+        float c = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; e++) c += dot4(x[e], y[e]);
+        c = row8_sum(c);
+        const float ab = a * b;
+        const float off = ab > 0.f ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
+        off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
+        float cs = 1.f, sn = 0.f, tc = 0.f;
+        if (off > tol) {
+            float t;
+            rotation(a, b, c, t, cs, sn);
+            tc = t * c;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const f32x4 xn = cs * x[e] - sn * y[e];
+            y[e] = sn * x[e] + cs * y[e];
+            x[e] = xn;
+        }
+        return tc;
+    };
+    auto load_col = [&](int col, f32x4 (&x)[E]) {
+        const float *p = G + (size_t)col * LDC + 4 * l;
+#pragma unroll
+        for (int e = 0; e < E; e++) x[e] = *reinterpret_cast<const f32x4 *>(p + 32 * e);
+    };
+    auto store_col = [&](int col, const f32x4 (&x)[E]) {
+        float *p = G + (size_t)col * LDC + 4 * l;
+#pragma unroll
+        for (int e = 0; e < E; e++) *reinterpret_cast<f32x4 *>(p + 32 * e) = x[e];
+    };
+
+    int sweep = 0;
+    for (; sweep < 40; sweep++) {
+        off_max = 0.f;
+        f32x4 x[E], y[E];
+        // exact squared norms of this wave's sixteen columns at the start of the sweep
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int col = 16 * wave + 8 * q + g;
+            load_col(col, x);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e++) s += dot4(x[e], x[e]);
+            s = row8_sum(s);
+            if (l == 0) nrm[col] = s;
+        }
+        // ---- the pairs inside blocks 2 wave (lane groups 0-3) and 2 wave + 1 (groups 4-7): seven wave-private rounds ---
+        {
+            const int base = 16 * wave + 8 * (g >> 2), k = g & 3;
+            for (int r = 0; r < 7; r++) {
+                const int pa = k == 0 ? 7 : (r + k) % 7, pb = k == 0 ? r : (r - k + 7) % 7;
+                const int ca = base + pa, cb = base + pb;
+                load_col(ca, x);
+                load_col(cb, y);
+                const float a = nrm[ca], b = nrm[cb];
+                const float tc = rotate(x, y, a, b);
+                store_col(ca, x);
+                store_col(cb, y);
+                if (l == 0) { nrm[ca] = a - tc; nrm[cb] = b + tc; }
+            }
+        }
+        __syncthreads();
+        // ---- the blocks meet: round r pairs block m with block r, and (r + k) mod m with (r - k) mod m ---------------
+        for (int r = 0; r < m; r++) {
+            const int ba = wave == 0 ? m : (r + wave) % m, bb = wave == 0 ? r : (r - wave + m) % m;
+            const int ca = 8 * ba + g;
+            load_col(ca, x);
+            float a = nrm[ca];
+#pragma unroll 1
+            for (int kk = 0; kk < 8; kk++) {
+                const int cb = 8 * bb + ((g + kk) & 7);
+                load_col(cb, y);
+                const float b = nrm[cb];
+                const float tc = rotate(x, y, a, b);
+                store_col(cb, y);
+                a -= tc;
+                if (l == 0) nrm[cb] = b + tc;
+            }
+            store_col(ca, x);
+            if (l == 0) nrm[ca] = a;
+            __syncthreads();
+        }
+        off_max = wmax(off_max);
+        if (lane == 0) red[wave] = off_max;
+        __syncthreads();
+        float mx = 0.f;
+        for (int w = 0; w < nw; w++) mx = fmaxf(mx, red[w]);
+        __syncthreads();
+        if (mx <= stop_cos) { sweep++; break; }              // see jacobi_body for why no verification sweep follows
+    }
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+
+    // ---- eigenvalues lambda = |g| - sigma, eigenvectors g / |g|, sorted descending ------------------------------------
+    float *lam = scratch, *inv = scratch + n;
+    int *rank = reinterpret_cast<int *>(scratch + 2 * n);
+    for (int j = wave; j < n; j += nw) {
+        float d = 0.f;
+        for (int i = lane; i < n; i += 64) { const float v = G[(size_t)j * LDC + i]; d += v * v; }
+        d = wsum(d);
+        if (lane == 0) { const float nr = sqrtf(d); lam[j] = nr - sigma; inv[j] = nr > 0.f ? 1.f / nr : 0.f; }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nthr) {
+        const float me = lam[j];
+        int rk = 0;
+        for (int k = 0; k < n; k++) {
+            const float o = lam[k];
+            rk += (o > me || (o == me && k < j)) ? 1 : 0;
+        }
+        rank[j] = rk;
+        evals[rk] = me;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += nthr) {
+        const int j = e / n, i = e % n;
+        Vout[(long)i * ldv + rank[j]] = G[(size_t)j * LDC + i] * inv[j];
+    }
+}
+
+template <int E>
+void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
+                       float stop_cos, float lam_cut, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_blk_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(jacobi_blk_kernel<E>, dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv, work,
+                       sweeps_out, stop_cos, lam_cut);
+}
+
 template <int E, bool PING>
 void launch_jacobi_seat8(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
                          float stop_cos, float lam_cut, hipStream_t s)
@@ -735,7 +926,13 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
     static const bool use_v2 = std::getenv("DLCO_JACOBI_V2") != nullptr;
     static const bool use_lp8 = std::getenv("DLCO_JACOBI_LP8") != nullptr;         // 8-lane seats for n <= 128 as well
     static const bool no_wide_seat = std::getenv("DLCO_JACOBI_NO_WIDE_SEAT") != nullptr;
-    if (n > J16_MAX_N && n <= 190 && !use_v1 && !no_wide_seat && jseat8_lds_bytes(n, false) <= 160 * 1024 - 1024) {
+    static const bool no_blk = std::getenv("DLCO_JACOBI_SEAT") != nullptr;    // A/B switch: the seat kernels of round 2
+    if (n >= 9 && n <= JBLK_MAX_N && !no_blk && !use_v1 && !use_v2 && !use_lp8) {
+        const int e = jblk_chunks(n);
+        if (e == 1) launch_jacobi_blk<1>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else if (e == 3) launch_jacobi_blk<3>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+        else launch_jacobi_blk<5>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
+    } else if (n > J16_MAX_N && n <= 190 && !use_v1 && !no_wide_seat && jseat8_lds_bytes(n, false) <= 160 * 1024 - 1024) {
         if (j16_chunks(n) == 5) launch_jacobi_seat8<5, false>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
         else launch_jacobi_seat8<6, false>(T, ldt, n, evals, V, ldv, work, sweeps_out, stop_cos, lam_cut, s);
     } else if (n <= J16_MAX_N && use_lp8 && !use_v1 && !use_v2) {

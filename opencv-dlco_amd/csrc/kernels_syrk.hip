@@ -78,7 +78,11 @@ union SyrkLds {
 // ---------------------------------------------------------------------------------------------------
 constexpr int NT8 = 512;
 
-template <bool PAIR, bool SLAB, bool BF16, int UNR = 16>
+// PACKED = true: C holds only the tiles on or above the diagonal, each a contiguous row-major 128 x 128 block, tile
+//               (bi, bj) at tile index bi*nt - bi*(bi-1)/2 + (bj - bi) (the layout the symmetric tracker product reads,
+//               kernels_bf16x2.hip): no mirrored store at all - half the bytes written, and 136 MB instead of 268 MB at
+//               F = 8192.  Diagonal tiles are stored whole and exactly symmetric.
+template <bool PAIR, bool SLAB, bool BF16, bool PACKED = false, int UNR = 16>
 __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
@@ -95,6 +99,9 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
     const int code = g.tile_map[t];
     const int bi = code >> 16, bj = code & 0xffff;
     const int i0 = bi * TB, j0 = bj * TB;
+    // where this tile's old and new contents live: a window of the full matrix, or its own packed block
+    float *const ctile = PACKED ? g.C + (long)(bi * g.nt - bi * (bi - 1) / 2 + (bj - bi)) * (TB * TB) : g.C + (long)i0 * g.ldc + j0;
+    const long cld = PACKED ? TB : g.ldc;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;                  // rows wm*64.., columns wn*32.. of the tile
@@ -151,13 +158,13 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
     float oldv[2][16];
     const bool use_old = (g.beta != 0.f);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int old_lane = 4 * lk * (int)g.ldc + lr;
+    const int old_lane = 4 * lk * (int)cld + lr;
     auto fetch_old = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float *rowb = g.C + (long)(i0 + (wave_u >> 2) * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + (j0 + (wave_u & 3) * 32);
+                const float *rowb = ctile + (long)((wave_u >> 2) * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * cld + (wave_u & 3) * 32;
                 oldv[a][r] = use_old ? rowb[old_lane] : 0.f;
             }
     };
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][4 * q + e] + g.beta * oldv[a][4 * q + e];
             const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;           // rows il0 .. il0+3
-            if (!SLAB && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+            if (!SLAB && !PACKED && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
 #pragma unroll
             for (int e = 0; e < 4; e++) lds.T[il0 + e][jl] = o[e];
         }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
             for (int e = 0; e < 4; e++)
                 if (cc + e < il) v[e] = lds.T[cc + e][il];
         }
-        *reinterpret_cast<f32x4 *>(&g.C[(long)(i0 + il) * g.ldc + (j0 + cc)]) = v;
+        *reinterpret_cast<f32x4 *>(&ctile[(long)il * cld + cc]) = v;
     }
     if (g.trace && tid == 0) {
         unsigned hw, xcc;
@@ -262,7 +269,42 @@ __global__ __launch_bounds__(256) void mirror_upper_kernel(float *C, long ldc, i
     }
 }
 
+// full symmetric F x F matrix <-> its packed upper tiles (see PACKED above); one workgroup per tile
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const float *C, long ldc, int nt, float *P, int unpack_into_C)
+{
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    float *tile = P + (long)(bi * nt - bi * (bi - 1) / 2 + (bj - bi)) * (TB * TB);
+    for (int f = threadIdx.x; f < TB * (TB / 4); f += 256) {
+        const int il = f / (TB / 4), cc = (f % (TB / 4)) * 4;
+        float *full = const_cast<float *>(C) + (long)(bi * TB + il) * ldc + bj * TB + cc;
+        if (!unpack_into_C) { *reinterpret_cast<f32x4 *>(tile + il * TB + cc) = *reinterpret_cast<const f32x4 *>(full); continue; }
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + il * TB + cc);
+        *reinterpret_cast<f32x4 *>(full) = v;
+        if (bi != bj) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) const_cast<float *>(C)[(long)(bj * TB + cc + e) * ldc + bi * TB + il] = v[e];
+        }
+    }
+}
+
 }  // namespace
+
+size_t syrk_packed_floats(int F) { const long nt = F / TB; return (size_t)(nt * (nt + 1) / 2) * TB * TB; }
+
+void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s)
+{
+    const int nt = F / TB;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(nt, nt), dim3(256), 0, s, C, ldc, nt, packed, 0);
+    DLCO_HIP(hipGetLastError());
+}
+
+void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s)
+{
+    const int nt = F / TB;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(nt, nt), dim3(256), 0, s, C, ldc, nt, const_cast<float *>(packed), 1);
+    DLCO_HIP(hipGetLastError());
+}
 
 void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s)
 {
@@ -315,10 +357,12 @@ static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count
 
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
-                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16)
+                  int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16,
+                  bool packed)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
     const bool slab = slab_cols > 0;
+    if (packed && slab) return false;
     if (slab && (slab_col0 % TB != 0 || slab_cols % TB != 0 || slab_col0 + slab_cols > F)) return false;
     SyrkDev g;
     g.D = D; g.ldd = ldd; g.ids = ids; g.ids2 = ids2; g.w = w; g.k_dev = k_dev; g.kmax = kmax; g.F = F;
@@ -340,13 +384,18 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         DLCO_CHECK(n_map == ntiles, -2, "syrk: tile map size");
     }
 #define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
-    if (bf16) {
+#define DLCO_SYRK_LAUNCH_PK(P, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, H, true>), dim3(ntiles), dim3(NT8), 0, s, g)
+    if (packed) {
+        if (bf16) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, true); else DLCO_SYRK_LAUNCH_PK(false, true); }
+        else { if (ids2) DLCO_SYRK_LAUNCH_PK(true, false); else DLCO_SYRK_LAUNCH_PK(false, false); }
+    } else if (bf16) {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, true); else DLCO_SYRK_LAUNCH(false, true, true); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, true); else DLCO_SYRK_LAUNCH(false, false, true); }
     } else {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, false); else DLCO_SYRK_LAUNCH(false, true, false); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, false); else DLCO_SYRK_LAUNCH(false, false, false); }
     }
+#undef DLCO_SYRK_LAUNCH_PK
 #undef DLCO_SYRK_LAUNCH
     DLCO_HIP(hipGetLastError());
     if (tracing) syrk_dump_trace(trace_path, trace_buf, ntiles, s);

@@ -197,6 +197,44 @@ def test_tracker_product_kernels(dlco, F, rows):
     ctx.close()
 
 
+def test_symmetric_product_on_packed_tiles_and_layout_round_trip(dlco):
+    """F = 8192, single rank: the dual average lives as its packed upper 128 x 128 tiles and the tracker's products fetch
+    every tile once (two workgroups per tile, paired on one XCD and in one step).  The symmetric kernel against float64,
+    row counts that exercise every tile count per block (1..5 x 32 rows), against the full-matrix kernel (same arithmetic,
+    another summation grouping), and using ONLY the upper triangle; then dlco_set_state -> dlco_get_dfavg through the
+    packed layout, and one fused SYRK + dual average on it against float64."""
+    F = 8192
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((F, F)).astype(np.float32)
+    G = np.triu(G) + np.triu(G, 1).T                                          # exactly symmetric
+    ctx = dlco.Context(F, 64, B=8)
+    Glow = np.triu(G) + np.tril(rng.standard_normal((F, F)).astype(np.float32), -1)   # garbage below the diagonal
+    for rows, mode in ((96, 3), (33, 3), (160, 3), (128, 3), (7, 3), (96, 4), (64, 4), (20, 4)):
+        X = rng.standard_normal((rows, F)).astype(np.float32)
+        want = X.astype(np.float64) @ G.astype(np.float64)
+        scale = np.abs(X).astype(np.float64) @ np.abs(G).astype(np.float64)
+        got = ctx.sym_product(X, Glow, mode=mode)
+        tol = 3e-5 if mode == 3 else 2e-6
+        assert (np.abs(got - want) <= tol * scale + 1e-30).all(), (rows, mode, float((np.abs(got - want) / scale).max()))
+        if rows <= 128:
+            full = ctx.sym_product(X, G, mode=mode - 2)
+            assert (np.abs(got - full) <= 2 * tol * scale + 1e-30).all()
+    del Glow
+    # layout round trip: what goes in through set_state comes back bit for bit (the lower triangle is the mirror)
+    ctx.set_state(3, G, None)
+    assert np.array_equal(ctx.dfavg(), G)
+    # one fused SYRK + dual average on the packed tiles
+    D, L = synth(64, F, k=8, seed=2)
+    ctx.set_data(D, L)
+    B = 8
+    pr, nr = np.arange(0, 16, 2, dtype=np.int32), np.arange(1, 17, 2, dtype=np.int32)
+    rho, kap = rng.integers(0, 9, B).astype(np.int32), rng.integers(0, 9, B).astype(np.int32)
+    got = ctx.grad_rda(pr, nr, rho, kap, 0.25, 0.5, G)
+    want = 0.25 * ((D[pr].astype(np.float64).T * rho) @ D[pr].astype(np.float64) - (D[nr].astype(np.float64).T * kap) @ D[nr].astype(np.float64)) + 0.5 * G
+    assert relmax(got, want) <= TOL_GRAD and np.array_equal(got, got.T)
+    ctx.close()
+
+
 def test_hinge_sum(small, ref):
     ctx = small[0]
     rng = np.random.default_rng(11)
@@ -236,7 +274,10 @@ def _psd_case(ref, F, seed, t, mu, gamma, rank_hint):
     return G, Ap, W
 
 
-@pytest.mark.parametrize("F,rank_hint", [(64, 9), (256, 40)])
+# F <= 160 is the dense case (the block is the whole space: the m x m solver alone decides the result): the widths walk
+# the block-Jacobi kernel's three column lengths (32 / 96 / 160), a column count that is not a multiple of 8 and an odd
+# number of 8-column blocks; F = 176 takes the wide seat kernel, F = 256 the tracker proper
+@pytest.mark.parametrize("F,rank_hint", [(64, 9), (256, 40), (24, 5), (96, 30), (100, 17), (128, 50), (160, 41), (176, 20)])
 def test_psd_project(dlco, ref, F, rank_hint):
     mu, gamma, t = 0.004, 0.5, 17
     G, Ap, Wref = _psd_case(ref, F, F + rank_hint, t, mu, gamma, rank_hint)
@@ -669,11 +710,11 @@ def test_uploaded_dual_average_is_symmetrised_from_its_upper_triangle(dlco):
 
 
 def test_tracker_block_above_1024_rows_and_the_batch_cap(dlco, ref):
-    """A global batch of 1100 + 1100 rows: at t = 0 (W = 0) every pair violates, the positive eigenspace of -dfAvg is
-    spanned by the ~1100 negative rows, and the tracker's block outgrows 1024 rows (the global-memory Jacobi).  One
+    """A global batch of 1300 + 1300 rows: at t = 0 (W = 0) every pair violates, the positive eigenspace of -dfAvg is
+    spanned by the ~1200 distinct negative rows of the batch, and the tracker's block outgrows 1024 rows (the global-memory Jacobi).  One
     teacher-forced step against the oracle's ssyevr.  A batch whose block could outgrow the 4096-row solver is refused
     at dlco_ctx_create with a message, not in the middle of a run."""
-    N, F, B = 6000, 2048, 1100
+    N, F, B = 20000, 2048, 1300                       # 8 000 training negatives: ~1 200 distinct rows among 1 300 draws
     D, L = synth(N, F, k=40, seed=77)
     mu, gamma = 0.0005, 0.5
     ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
@@ -690,12 +731,13 @@ def test_tracker_block_above_1024_rows_and_the_batch_cap(dlco, ref):
     assert relmax(ctx.dfavg(), after["dfavg"]) <= 5e-6
     W = ctx.W()
     r = W.shape[0]
-    assert r > 900, r
+    block = ctx.eig_stats()["block_rows"]
+    assert r > 1000 and block >= 1024, (r, block)        # the trimmed block; during the step it held r + 32 or more rows
     nz = int((np.abs(W).max(axis=1) > 0).sum())
     assert nz == r
     assert abs(r - after["r"]) <= 2
-    err_a = _check_A("B=1100 first step F=2048", ctx.A(), after["A"])
-    print("B=1100 first step: rank %d (oracle %d), err_A %.2e" % (r, after["r"], err_a))
+    err_a = _check_A("B=1300 first step F=2048", ctx.A(), after["A"])
+    print("B=1300 first step: rank %d (oracle %d), err_A %.2e" % (r, after["r"], err_a))
     assert ctx.counters()["nonconverged"] == 0
     ctx.close()
     tr.close()

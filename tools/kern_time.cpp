@@ -51,6 +51,20 @@ int main(int argc, char **argv)
         const float c8 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 8); });
         const float t2 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 0, nullptr, true); });
         const float t3 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s0, 0, pl2.p, true); });
+        {   // symmetric G as packed upper tiles: every tile fetched once (skinny_sym_kernel)
+            DevBuf<float> Gp, slab4, X160, out160; DevBuf<char> qh, ql;
+            Gp.alloc(syrk_packed_floats(F)); slab4.alloc((size_t)4 * 160 * F); X160.alloc((size_t)160 * F); out160.alloc((size_t)160 * F);
+            qh.alloc(bf16x2_plane_bytes(160, F)); ql.alloc(bf16x2_plane_bytes(160, F));
+            hipMemcpy(X160.p, h.data(), (size_t)128 * F * 4, hipMemcpyHostToDevice);
+            hipMemcpy(X160.p + (size_t)128 * F, h.data(), (size_t)32 * F * 4, hipMemcpyHostToDevice);
+            syrk_pack_upper(C.p, F, F, Gp.p, s0);
+            const float y2 = time_ms(s0, 30, [&] { skinny_product_sym(X.p, F, M, Gp.p, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab4.p, s0); });
+            const float y3 = time_ms(s0, 30, [&] { skinny_product_sym(X.p, F, M, Gp.p, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab4.p, s0, pl2.p); });
+            const float y5 = time_ms(s0, 30, [&] { skinny_product_sym(X160.p, F, 160, Gp.p, F, 1.f, out160.p, F, nullptr, 0.f, nullptr, 0.f, qh.p, ql.p, slab4.p, s0); });
+            const float z5 = time_ms(s0, 30, [&] { skinny_product_bf16x2(X160.p, F, 160, C.p, F, F, F, 1.f, out160.p, F, nullptr, 0.f, nullptr, 0.f, qh.p, ql.p, slab4.p, s0); });
+            std::printf("SYMMETRIC product on packed upper tiles (136 MB): M=96 two-way %.1f us, three-way %.1f us; M=160 two-way %.1f us (full-matrix kernel %.1f us)  [split + kernel + reduce]\n",
+                        y2 * 1e3, y3 * 1e3, y5 * 1e3, z5 * 1e3);
+        }
         std::printf("product on a TILED matrix (128 x 128 tiles contiguous): two-way %.1f us (%.2f TB/s), three-way %.1f us (%.2f TB/s)\n", t2 * 1e3,
                     4.0 * F * F / (t2 * 1e-3) / 1e12, t3 * 1e3, 4.0 * F * F / (t3 * 1e-3) / 1e12);
         std::printf("product M=%d F=%d: two-way %.1f us (%.2f TB/s), three-way %.1f us (%.2f TB/s), two-way ks=8 %.1f us  [split + kernel + reduce]\n", M, F,
@@ -61,7 +75,7 @@ int main(int argc, char **argv)
     hipStreamCreate(&s);
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (int n : {32, 64, 70, 96, 97, 128}) {
+    for (int n : {32, 64, 70, 96, 97, 128, 150, 160}) {
         // ---- Cholesky inverse on M = B B^T (rows of B random, nearly orthogonal after scaling) ----
         const int K = 512, ld = 1024;
         std::vector<double> B((size_t)n * K);
@@ -73,6 +87,7 @@ int main(int argc, char **argv)
                 for (int k = 0; k < K; k++) acc += B[(size_t)i * K + k] * B[(size_t)j * K + k];
                 M[(size_t)i * ld + j] = (float)(acc / K);
             }
+        if (n <= CHOL_INV_MAX_N) {
         DevBuf<float> dM, dL; DevBuf<int> dead;
         dM.alloc(M.size()); dL.alloc(M.size()); dead.alloc(128);
         hipMemcpy(dM.p, M.data(), M.size() * 4, hipMemcpyHostToDevice);
@@ -92,6 +107,7 @@ int main(int argc, char **argv)
                 err = std::max(err, std::fabs(acc - (i == j ? 1.0 : 0.0)));
             }
         std::printf("chol_inverse128 n=%3d  %.1f us  |Linv M Linv^T - I|max = %.2e\n", n, ms * 1e3, err);
+        }
 
         // ---- Jacobi on a nearly diagonal symmetric matrix (steady-state Rayleigh-Ritz) ------------
         std::vector<float> T((size_t)n * ld, 0.f);
