@@ -427,7 +427,7 @@ class Context:
 
     # ---- measurement ------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._ck(self.L.dlco_profile_enable(self.h, 1 if on else 0))
+        self._ck(self.L.dlco_profile_enable(self.h, int(on)))          # True / 1: every kernel group, 2: the gradient SYRK only
 
     def profile_read(self, kernel="grad_syrk"):
         n, ms = C.c_int64(), C.c_double()

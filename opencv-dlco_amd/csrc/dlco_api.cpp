@@ -50,7 +50,6 @@ struct dlco_ctx {
     int w_cap = 0;
     std::vector<int32_t> h_pos_rows, h_neg_rows;
     int32_t *pin_ids = nullptr;      // pinned staging of the sampled row ids: [2 slots][2B], no sync after the upload
-    int *pin_k = nullptr;            // pinned read-back of the active row count
     uint32_t upload_ctr = 0;
     // sampled row ids on the device, one allocation [pos: B | neg: B | own pos slots: Bl | own neg slots: Bl]
     // filled by a single upload per step
@@ -336,6 +335,7 @@ void step_begin(dlco_ctx *c)
     std::memcpy(slot + B, c->h_neg_rows.data(), B * sizeof(int32_t));
     std::memcpy(slot + 2 * B, c->h_pos_rows.data() + c->lo, Bl * sizeof(int32_t));
     std::memcpy(slot + 2 * B + Bl, c->h_neg_rows.data() + c->lo, Bl * sizeof(int32_t));
+    // (letting the kernels read the pinned slot directly instead of this copy was measured slower: 0.852 against 0.838 ms per step)
     DLCO_HIP(hipMemcpyAsync(c->ids_all.p, slot, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     // P1+P2 on this rank's slots -> its slice of the exchange buffer
     project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl);
@@ -386,14 +386,10 @@ void step_finish(dlco_ctx *c)
     }
     const float cscale = (float)(std::sqrt((double)c->t + 1.0) / (double)c->cfg.gamma);
     bool conv = true;
-    // rows that entered this rank's SYRK this step: read back with the tracker's own synchronisation
-    DLCO_HIP(hipMemcpyAsync(c->pin_k, c->k_active.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // rows that entered this rank's SYRK this step: the count rides in the tracker's own read-back of its Ritz block
     c->r = c->eig->update(c->dfavg.p, c->cfg.mu, cscale, c->W.p, &c->traceA, &conv);
     if (!conv) { c->nonconv_steps++; c->nonconv_window++; }
-    // The copy above precedes, on the same stream, the kernel that publishes the tracker's Ritz block (or the
-    // block's own D2H copy): update() returns only after it has seen that block, so the count has landed.
-    // (update() always runs at least one Rayleigh-Ritz pass, i.e. one such read-back.)
-    c->active_rows_sum += *c->pin_k;
+    c->active_rows_sum += c->eig->readback_extra();      // as of the last pass of this update: this step's count
     c->steps_run++;
     c->t++;
     c->phase = 0;
@@ -540,8 +536,6 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const int B = c->B;
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
         DLCO_HIP(hipHostMalloc((void **)&c->pin_ids, (size_t)2 * (2 * B + 2 * c->Bl) * sizeof(int32_t)));
-        DLCO_HIP(hipHostMalloc((void **)&c->pin_k, 4 * sizeof(int), hipHostMallocCoherent));
-        c->pin_k[0] = 0;
         c->ids_all.alloc((size_t)2 * B + 2 * c->Bl);
         c->pos_rows.p = c->ids_all.p; c->neg_rows.p = c->ids_all.p + B; c->local_ids.p = c->ids_all.p + 2 * B;
         c->rho.alloc(B); c->kappa.alloc(B);
@@ -550,6 +544,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
+        c->eig->set_readback_extra(c->k_active.p);
         c->dscal.alloc(4);
         // column-sharded dual average (world > 1, or forced for single-rank testing of the path)
         c->shard = cfg->shard != 0 && (cfg->world > 1 || std::getenv("DLCO_FORCE_SHARD") != nullptr);
@@ -580,7 +575,6 @@ void dlco_ctx_destroy(dlco_ctx *c)
     delete c->hostcomm;
     if (c->roc) roc_work_destroy(c->roc);
     if (c->pin_ids) (void)hipHostFree(c->pin_ids);
-    if (c->pin_k) (void)hipHostFree(c->pin_k);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1207,6 +1201,7 @@ int dlco_profile_enable(dlco_ctx *c, int32_t on)
     return guarded(c, [&] {
         c->prof.reset();
         c->prof.on = on != 0;
+        c->prof.mask = on == 2 ? (1u << PROF_GRAD_SYRK) : ~0u;
     });
 }
 

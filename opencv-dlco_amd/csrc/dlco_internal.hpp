@@ -65,14 +65,17 @@ enum ProfSlot { PROF_GRAD_SYRK = 0, PROF_EIG_PRODUCT = 1, PROF_JACOBI = 2, PROF_
 
 struct Profiler {
     bool on = false;
+    unsigned mask = ~0u;          // slots that record (bit per ProfSlot): every record costs a few microseconds of queue time
     hipStream_t s = nullptr;
     struct Rec { std::vector<hipEvent_t> ev; size_t used = 0; double ms = 0.0; int64_t n = 0; };
     Rec rec[PROF_SLOTS];
     ~Profiler() { for (auto &r : rec) for (hipEvent_t e : r.ev) (void)hipEventDestroy(e); }
     void mark(int slot) {
-        if (!on) return;
+        if (!on || !((mask >> slot) & 1u)) return;
         Rec &r = rec[slot];
-        if (r.used == r.ev.size()) { hipEvent_t e; DLCO_HIP(hipEventCreate(&e)); r.ev.push_back(e); }
+        // timing-only events: without the system-scope fence a default event carries (hipEventDisableSystemFence), a
+        // record is a time stamp in the queue instead of a cache flush - the default form cost ~6 us of idle GPU per record
+        if (r.used == r.ev.size()) { hipEvent_t e; DLCO_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence)); r.ev.push_back(e); }
         DLCO_HIP(hipEventRecord(r.ev[r.used++], s));
         if (r.used >= 8192 && (r.used % 2) == 0) drain(slot);
     }
@@ -251,7 +254,8 @@ constexpr int CHOL_INV_MAX_N = 128;
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s);
 // row norms of (Y - theta_i X) and of X
 // n floats -> pinned host memory, then *flag_host = seq with system-scope release (the host polls flag_host)
-void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s);
+void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
+                   const int *extra_dev = nullptr, int *extra_host = nullptr);   // extra: one device int copied along
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
 void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);

@@ -46,7 +46,7 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     slab_floats_ = std::min(slab_floats_, (size_t)64 << 20);
     slab_floats_ = std::max(slab_floats_, (size_t)cap_ * F_);
     slab_.alloc(slab_floats_);
-    pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats); the last 16 hold the poll flag
+    pin_floats_ = (size_t)3 * cap_ + 64;                  // >= the Ritz block (2*(cap+8)+1 floats); the last 16 hold the poll flag, the 16 before them the caller's extra word
     // coherent (fine-grained) on purpose: the host polls a sequence number that a kernel writes with a
     // system-scope release; with HIP_HOST_COHERENT=0 a default allocation would only be seen at a sync
     DLCO_HIP(hipHostMalloc((void **)&pin_, pin_floats_ * sizeof(float), hipHostMallocCoherent));
@@ -471,7 +471,8 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             // costs a few microseconds where copy + hipStreamSynchronize cost tens (one read-back per pass)
             unsigned *flag = reinterpret_cast<unsigned *>(pin_ + pin_floats_ - 16);
             const unsigned seq = ++publish_seq_;
-            publish_block(ritz_block_.p, pin_, (int)blk, flag, seq, s_);
+            int *extra_host = reinterpret_cast<int *>(pin_ + pin_floats_ - 32);
+            publish_block(ritz_block_.p, pin_, (int)blk, flag, seq, s_, extra_dev_, extra_host);
             const auto t0 = std::chrono::steady_clock::now();
             bool seen = false;
             for (long spins = 0;; spins++) {
@@ -484,8 +485,10 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             }
         } else {
             DLCO_HIP(hipMemcpyAsync(pin_, ritz_block_.p, blk * sizeof(float), hipMemcpyDeviceToHost, s_));
+            if (extra_dev_) DLCO_HIP(hipMemcpyAsync(pin_ + pin_floats_ - 32, extra_dev_, sizeof(int), hipMemcpyDeviceToHost, s_));
             DLCO_HIP(hipStreamSynchronize(s_));
         }
+        if (extra_dev_) extra_val_ = *reinterpret_cast<int *>(pin_ + pin_floats_ - 32);
         std::memcpy(h_theta_.data(), pin_, (size_t)m_ * sizeof(float));
         std::memcpy(h_res_.data(), pin_ + (cap_ + 8), (size_t)m_ * sizeof(float));
         st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * (cap_ + 8));

@@ -45,6 +45,10 @@ public:
     void set_shard(const ShardComm *sc) { shard_ = sc; }
     // Every G handed to update() is the PACKED upper-tile form (syrk_packed_floats(F) floats, kernels_syrk.hip): the
     // products take the symmetric kernel that fetches each tile once.  Only valid where packed_supported() holds.
+    // One device int the caller wants read back with every Ritz block (the step's active row count): it rides in the
+    // block's read-back instead of a copy of its own.  readback_extra() is its value as of the last update().
+    void set_readback_extra(const int *dev) { extra_dev_ = dev; }
+    int readback_extra() const { return extra_val_; }
     void set_packed(bool on) { packed_ = on; }
     bool packed() const { return packed_; }
     static bool packed_supported(int F) { return F == 8192 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }
@@ -67,6 +71,8 @@ private:
 
     int F_, cap_, guard_, max_iter_;
     float tol_;
+    const int *extra_dev_ = nullptr;
+    int extra_val_ = 0;
     bool packed_ = false;
     bool cold_ = true;               // no update since construction / reset(): the next one converges to tol_ / 4
     hipStream_t s_;

@@ -555,6 +555,10 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0][t], bh, acc[t], 0, 0, 0);
         }
     };
+    // (Two fragment sets per wave - the second K step's reads in flight under the first one's MFMAs - were measured and
+    // changed nothing: 59.3 against 59.6 us per pass.  Ablation of this kernel at M = 96, two-way, per pass incl. 10 us of
+    // split + reduce: 60 us as is, 61 us without the G loads, 44 us without the compute waves' work, 32 us with neither -
+    // the loaders' LDS stores and the compute waves' LDS reads and conversions add up rather than overlap.)
     Frag fa;
     __syncthreads();
     for (int cc = 0; cc < nchunks; cc++) {

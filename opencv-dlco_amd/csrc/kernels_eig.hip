@@ -434,17 +434,20 @@ void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *L
 
 // Copies n floats into pinned host memory and then raises a sequence number there (system-scope release): the
 // host polls the number instead of paying a stream synchronisation for a read-back of a few hundred bytes.
-__global__ __launch_bounds__(256) void publish_block_kernel(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq)
+__global__ __launch_bounds__(256) void publish_block_kernel(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq,
+                                                            const int *extra_dev, int *extra_host)
 {
     for (int i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
+    if (extra_dev && threadIdx.x == 0) *extra_host = *extra_dev;      // one more word the caller wants back (no copy of its own)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s)
+void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s, const int *extra_dev,
+                   int *extra_host)
 {
-    hipLaunchKernelGGL(publish_block_kernel, dim3(1), dim3(256), 0, s, src, dst_host, n, flag_host, seq);
+    hipLaunchKernelGGL(publish_block_kernel, dim3(1), dim3(256), 0, s, src, dst_host, n, flag_host, seq, extra_dev, extra_host);
     DLCO_HIP(hipGetLastError());
 }
 
