@@ -75,7 +75,9 @@ int main(int argc, char **argv)
     hipStreamCreate(&s);
     std::mt19937 rng(7);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (int n : {32, 64, 70, 96, 97, 128, 150, 160}) {
+    const bool big = argc > 2 && std::string(argv[2]) == "big";      // `kern_time small big`: the transient's block sizes too
+    for (int n : {32, 64, 70, 96, 97, 128, 150, 160, 200, 256, 400, 800}) {
+        if (n > 160 && !big) break;
         // ---- Cholesky inverse on M = B B^T (rows of B random, nearly orthogonal after scaling) ----
         const int K = 512, ld = 1024;
         std::vector<double> B((size_t)n * K);
@@ -119,7 +121,7 @@ int main(int argc, char **argv)
         DevBuf<float> dT, dV, ev, work; DevBuf<int> sw;
         dT.alloc(T.size()); dV.alloc(T.size()); ev.alloc(n + 8); work.alloc(jacobi_work_floats(n)); sw.alloc(4);
         hipMemcpy(dT.p, T.data(), T.size() * 4, hipMemcpyHostToDevice);
-        const float msj = time_ms(s, 100, [&] { jacobi_eigh(dT.p, ld, n, ev.p, dV.p, ld, work.p, sw.p, s); });
+        const float msj = time_ms(s, n > 160 ? 5 : 100, [&] { jacobi_eigh(dT.p, ld, n, ev.p, dV.p, ld, work.p, sw.p, s); });
         int sweeps = 0;
         hipMemcpy(&sweeps, sw.p, 4, hipMemcpyDeviceToHost);
         std::vector<float> V(T.size()), e(n);
