@@ -465,7 +465,7 @@ def main():
     sq = committed_profile("r3_pmc_sq.json") or committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
     mfma_busy = None
     try:
-        mfma_busy = sq["kernels"]["syrk_rda_kernel"]["mfma_util"]
+        mfma_busy = sq["kernels"]["syrk_rda_kernel"]["mfma_util"]      # committed --pmc pass of this command (tools/collect_sq.sh)
     except Exception:
         pass
     # per pair-row 2F^2 + 2Fr flops (projection + gradient, dense)
@@ -489,7 +489,7 @@ def main():
             "workload": "pj-learn %s: %d pair-rows x PR-dim %d, batch %d+%d per GPU (global %d+%d), mu=%g gamma=%g, %s, rank %d after %d steps"
                         % (wl["name"], N, F, B // world, B // world, B, B, wl["mu"], wl["gamma"],
                            "bf16 MFMA + fp32 accumulate in the gradient, projection and statistics GEMMs (configs[4] variant), fp32 elsewhere"
-                           if args.bf16 else "fp32", rank_now, args.burn_in + args.warmup + args.steps)
+                           if args.bf16 else "fp32", rank_now, args.burn_in + args.warmup + args.steps + bsteps)
                         + (" [pair mode: %d patch descriptors + Indices, differences formed in the kernels]" % args.patches
                            if args.pair_mode else ""),
             "generator": {k_: wl[k_] for k_ in ("latent", "sigma_pos", "sigma_neg", "noise", "jitter", "seed")},

@@ -178,7 +178,9 @@ void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream
 // (two-way split) / 96 (three-way, plane_lo2 != nullptr).  slab: >= 4*M*F floats.  Returns false for other shapes.
 bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, int F, float alpha, float *C, long ldc,
                         const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo, float *slab,
-                        hipStream_t s, void *plane_lo2 = nullptr);
+                        hipStream_t s, void *plane_lo2 = nullptr, bool planes_ready = false, bool emit_planes = false);
+// planes_ready: plane_hi / plane_lo already hold the two-way planes of X (skip the split); emit_planes: the reduction also
+// writes the two-way planes of the RESULT into plane_hi / plane_lo (the next product of a Chebyshev chain takes it as X)
 // C[M][N] = alpha * X[M][K] * G[K][N] + b1*E1 + b2*E2 for M <= 128 (single launch, K split over
 // the waves of a workgroup, deterministic).  Returns false when the shape is not supported.
 bool skinny_product_f32(const float *X, long ldx, int M, int x_rows_alloc, const float *G, long ldg, int N, int K,

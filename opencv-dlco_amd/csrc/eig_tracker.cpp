@@ -114,6 +114,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     // in ONE pass over G - and 96 with the three-way split; a sharded rank's slab kernel 128)
     const int one_pass = (approx && !shard_ && F_ % 512 == 0) ? 160 : (packed_ ? 96 : 128);   // (symmetric three-way kernel: 96 rows)
     if (rows > one_pass && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
+        chain_next_ = false;                                     // row chunks share the plane buffers: no carried planes
         const int step = approx ? (rows <= 2 * one_pass ? (rows / 2 + 31) / 32 * 32 : one_pass) : 96;
         for (int r0 = 0; r0 < rows; r0 += step) {
             const int nr = std::min(step, rows - r0);
@@ -127,8 +128,13 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         // G = packed upper tiles: the symmetric kernel (every tile fetched once); two-way split for the filter, three-way
         // for the exact products (rows <= 96 there: the chunking above)
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
+        // inside a filter chain the planes of X are those the previous product's reduction emitted (chain_next_)
+        const bool ready = approx && chain_planes_of_ == X && chain_rows_ == rows;
+        const bool emit = approx && chain_next_;
         const bool ok = skinny_product_sym(X, F_, rows, G, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p, plane_lo_.p, slab_.p, s_,
-                                           approx ? nullptr : plane_lo2_.p);
+                                           approx ? nullptr : plane_lo2_.p, ready, emit);
+        chain_planes_of_ = emit ? out : nullptr;                 // (a product without `emit` has overwritten the planes with X's)
+        chain_rows_ = rows;
         if (prof_) prof_->end(PROF_EIG_PRODUCT);
         DLCO_CHECK(ok, -2, "eig tracker: the symmetric product rejected a shape of the packed layout");
         return;
@@ -365,7 +371,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     float theta_top = have_theta_ ? h_theta_[0] : 0.f;
     float block_min = have_theta_ ? std::min(h_theta_[m_ - 1], mu) : mu;
     steps_since_lo_++;
-    const int period = st_.updates < 20 ? 1 : (st_.updates < 200 ? 5 : 20);
+    const int period = st_.updates < 20 ? 1 : (st_.updates < 200 ? 5 : (st_.updates < 400 ? 20 : 50));   // lambda_max(G) drifts as 1/t
     if (!have_lo_) refresh_lower_bound(G, 30, theta_top);
     else if (steps_since_lo_ >= period) refresh_lower_bound(G, 6, theta_top);
 
@@ -413,12 +419,17 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             } else {
                 const float *prev = Q_;
                 float *cur = pick({Q_});
+                chain_planes_of_ = nullptr;
+                chain_next_ = d >= 2;                            // the result is the X of the next product: emit its planes
                 product(Q_, m_, G, -1.0f / e0, cur, Q_, -c0 / e0, nullptr, 0.f, true);
                 for (int k = 2; k <= d; k++) {
                     float *nxt = pick({prev, cur});
+                    chain_next_ = k < d;
                     product(cur, m_, G, -2.0f / e0, nxt, cur, -2.0f * c0 / e0, prev, -1.0f, true);
                     prev = cur; cur = nxt;
                 }
+                chain_next_ = false;
+                chain_planes_of_ = nullptr;
                 Z = cur;
             }
             last_deg_ = d;

@@ -74,6 +74,9 @@ private:
     const int *extra_dev_ = nullptr;
     int extra_val_ = 0;
     bool packed_ = false;
+    const float *chain_planes_of_ = nullptr;   // the matrix whose two-way planes sit in plane_hi_/plane_lo_ (emitted by a reduction)
+    int chain_rows_ = 0;
+    bool chain_next_ = false;        // the product being issued feeds the next one of a filter chain
     bool cold_ = true;               // no update since construction / reset(): the next one converges to tol_ / 4
     hipStream_t s_;
     int m_ = 0;                      // rows currently in the block

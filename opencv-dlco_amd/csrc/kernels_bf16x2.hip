@@ -22,6 +22,7 @@
 // HBM-bound read of G as well.
 #include "dlco_internal.hpp"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace dlco {
@@ -388,6 +389,42 @@ __global__ __launch_bounds__(RK_T) void skinny_rows_kernel(Bf2Dev g)
     }
 }
 
+// The ordered sum of the K-slice slabs (splitk_reduce_f32's arithmetic: slices added in order, then alpha, E1, E2) that ALSO
+// emits the two-way split planes of its result in fragment order: inside the Chebyshev recurrence the output of one filter
+// product is the X of the next, so the next product needs no split_x_kernel launch of its own.  One thread per 8 consecutive
+// columns of a row: 32-byte slab reads (a wave covers 2 KiB of a row), one 16-byte store per plane.
+__global__ __launch_bounds__(256) void reduce_split_kernel(const float *slab, int split, int M, int MT, int N, float *C, long ldc, float alpha,
+                                                           const float *E1, float b1, const float *E2, float b2, bf16x8 *hi, bf16x8 *lo)
+{
+    const long total = (long)M * N, q = N >> 3;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)M * q; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / q), k8 = (int)(e % q), j = k8 * 8;
+        const float *p = slab + (long)i * N + j;
+        f32x4 s0 = *reinterpret_cast<const f32x4 *>(p), s1 = *reinterpret_cast<const f32x4 *>(p + 4);
+        for (int z = 1; z < split; z++) {
+            s0 += *reinterpret_cast<const f32x4 *>(p + (long)z * total);
+            s1 += *reinterpret_cast<const f32x4 *>(p + (long)z * total + 4);
+        }
+        const long idx = (long)i * ldc + j;
+        f32x4 o0 = alpha * s0, o1 = alpha * s1;
+        if (E1) { o0 += b1 * *reinterpret_cast<const f32x4 *>(E1 + idx); o1 += b1 * *reinterpret_cast<const f32x4 *>(E1 + idx + 4); }
+        if (E2) { o0 += b2 * *reinterpret_cast<const f32x4 *>(E2 + idx); o1 += b2 * *reinterpret_cast<const f32x4 *>(E2 + idx + 4); }
+        *reinterpret_cast<f32x4 *>(C + idx) = o0;
+        *reinterpret_cast<f32x4 *>(C + idx + 4) = o1;
+        bf16x8 h, l;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float x = u < 4 ? o0[u & 3] : o1[u & 3];
+            h[u] = (__bf16)x;
+            l[u] = (__bf16)(x - (float)h[u]);
+        }
+        // plane entry ((k16 * MT + tile) * 64 + lane): row tile*32 + (lane & 31), columns k16*16 + 8*(lane >> 5) .. +7
+        const long t = ((long)(k8 >> 1) * MT + (i >> 5)) * 64 + (i & 31) + 32 * (k8 & 1);
+        hi[t] = h;
+        lo[t] = l;
+    }
+}
+
 // ---- symmetric G stored as its packed upper tiles: every tile leaves HBM once ------------------------------------------
 // out[:, I] = sum_J X[:, J] G[J][I] over tile blocks; G[J][I] is the stored tile (I, J) read along its rows when I <= J
 // ("direct", exactly the chunk of skinny_rows_kernel), or the stored tile (J, I) read along its COLUMNS when J < I
@@ -697,14 +734,16 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
 // The same product for a symmetric G given as its packed upper tiles (see skinny_sym_kernel).
 bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, int F, float alpha, float *C, long ldc,
                         const float *E1, float b1, const float *E2, float b2, void *plane_hi, void *plane_lo, float *slab,
-                        hipStream_t s, void *plane_lo2)
+                        hipStream_t s, void *plane_lo2, bool planes_ready, bool emit_planes)
 {
     const int mt = (M + 31) / 32;
     if (F != 8192 || M < 1 || mt > 5 || (mt >= 4 && plane_lo2)) return false;
     if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || (reinterpret_cast<uintptr_t>(Gpacked) & 15) != 0) return false;
+    if ((planes_ready || emit_planes) && plane_lo2) return false;       // the carried planes are the two-way ones
     const long total = (long)(F / 16) * mt * 64;
-    hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, F,
-                       static_cast<bf16x8 *>(plane_hi), static_cast<bf16x8 *>(plane_lo), static_cast<bf16x8 *>(plane_lo2));
+    if (!planes_ready)
+        hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, ldx, M, mt, F,
+                           static_cast<bf16x8 *>(plane_hi), static_cast<bf16x8 *>(plane_lo), static_cast<bf16x8 *>(plane_lo2));
     SymDev g;
     g.M = M; g.K = F;
     g.xhi = static_cast<const bf16x8 *>(plane_hi); g.xlo = static_cast<const bf16x8 *>(plane_lo); g.xlo2 = static_cast<const bf16x8 *>(plane_lo2);
@@ -721,7 +760,16 @@ bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, i
         else launch_sym<5, 2>(g, s);
     }
     DLCO_HIP(hipGetLastError());
-    splitk_reduce_f32(slab, 4, M, F, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
+    if (emit_planes && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        // the product kernel has read the planes of X: they now receive the planes of the result, rows up to 32 mt zeroed by
+        // the split of the first product of the chain (rows >= M of a tile are never written here and stay zero)
+        const long work = (long)M * (F / 8);
+        hipLaunchKernelGGL(reduce_split_kernel, dim3((unsigned)std::min<long>((work + 255) / 256, 4096)), dim3(256), 0, s, slab, 4, M, mt, F, C, ldc,
+                           alpha, E1, b1, E2, b2, static_cast<bf16x8 *>(plane_hi), static_cast<bf16x8 *>(plane_lo));
+        DLCO_HIP(hipGetLastError());
+    } else {
+        splitk_reduce_f32(slab, 4, M, F, C, ldc, alpha, 0.f, E1, b1, E2, b2, s);
+    }
     return true;
 }
 

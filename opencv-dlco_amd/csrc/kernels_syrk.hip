@@ -14,8 +14,9 @@
 // row ids one tile ahead of the data so that the gather's two dependent loads never sit in
 // the same iteration.  The hot loop is branch-free; the row list is zero-padded to the tile
 // depth by the kernel that builds it.  Epilogue: dual-average update in registers, direct
-// store of the tile, transposed store through LDS as whole 512-byte rows.  Exact fp32
-// (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain).
+// store of the tile, transposed store through LDS as whole 512-byte rows.  fp32 results: by default from
+// the bf16 matrix cores with both operands split three ways at staging time (see PRE in the kernel), or
+// from v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain) with DLCO_SYRK_FP32=1.
 #include "dlco_internal.hpp"
 
 #include <mutex>
@@ -52,8 +53,13 @@ struct SyrkDev {
     unsigned long long *trace;    // developer aid (DLCO_SYRK_TRACE): 6 words per workgroup, see syrk_rda_f32
 };
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
 union SyrkLds {
     struct { float A[2][KB][LD]; float B[2][KB][LD]; } st;    // 67,584 B
+    // three-way split mode: per stage and operand three bf16 planes (hi, mid, lo) of a 16-deep K block, entry
+    // [k / 4][column] = the four consecutive k of that column (8 bytes): an MFMA fragment is two 8-byte reads
+    struct { bf16x4 A[2][3][4][TB]; bf16x4 B[2][3][4][TB]; } sp;   // 49,152 B
     float T[TB][TLD];                                          // 66,048 B
 };
 
@@ -82,7 +88,7 @@ constexpr int NT8 = 512;
 //               (bi, bj) at tile index bi*nt - bi*(bi-1)/2 + (bj - bi) (the layout the symmetric tracker product reads,
 //               kernels_bf16x2.hip): no mirrored store at all - half the bytes written, and 136 MB instead of 268 MB at
 //               F = 8192.  Diagonal tiles are stored whole and exactly symmetric.
-template <bool PAIR, bool SLAB, bool BF16, bool PACKED = false, int UNR = 16>
+template <bool PAIR, bool SLAB, int BF16, bool PACKED = false, int UNR = 16>
 __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 {
     __shared__ __attribute__((aligned(16))) SyrkLds lds;
@@ -107,8 +113,14 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
     const int wm = wave >> 2, wn = wave & 3;                  // rows wm*64.., columns wn*32.. of the tile
     const int lr = lane & 31, lk = lane >> 5;
 
+    // BF16 == 3: fp32 results from the bf16 matrix cores.  Every staged value is split three ways, x = hi + mid + lo (all
+    // 24 mantissa bits), ONCE, by the thread that gathers it, and stored as three bf16 planes; the K loop then forms the
+    // six products down to 2^-16 (hh, hm, mh, mm, hl, lh; smallest first, fp32 accumulation) - 6/16 of the fp32-MFMA
+    // time, no conversion work in front of the MFMAs, 16-deep K blocks (49 KB of LDS: still two workgroups per CU).
+    constexpr bool PRE = BF16 == 3;
+    constexpr int KD = PRE ? 16 : KB;
     const int kact = min(*g.k_dev, g.kmax);
-    const int nk = (kact + KB - 1) / KB;
+    const int nk = (kact + KD - 1) / KD;
 
     f32x16 acc[2];
 #pragma unroll
@@ -116,12 +128,29 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
 
-    // loader mapping: 2 float4 per operand per thread; rows rbase, rbase + 16 of the K block
+    // loader mapping (fp32 / bf16-once): 2 float4 per operand per thread; rows rbase, rbase + 16 of the K block
     const int c4 = tid & 31, rbase = tid >> 5;
     int32_t id_nx[2], id2_nx[2];
     float w_nx[2];
     f32x4 ra[2], rb[2];
+    // loader mapping (three-way split): wave -> (operand, group of four K rows), lane -> a pair of columns; the four
+    // rows of a wave are wave-uniform, the lane loads 8 bytes of each
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int p_op = wave >> 2, p_kq = wave & 3, p_c2 = lane;
+    int32_t pid[4], pid2[4];
+    float pw[4], pwl[4];                                      // weights of the rows whose ids / whose values are held
+    f32x2 pv[4], pv2[4];
     auto load_ids = [&](int kt) {
+        if (PRE) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = kt * KD + p_kq * 4 + u;
+                pid[u] = g.ids[k];
+                if (PAIR) pid2[u] = g.ids2[k];
+                pw[u] = p_op == 0 ? g.w[k] : 1.0f;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int k = kt * KB + rbase + 16 * u;
@@ -131,6 +160,16 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         }
     };
     auto load_rows = [&]() {
+        if (PRE) {
+            const int col = (p_op == 0 ? i0 : j0) + 2 * p_c2;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                pv[u] = *reinterpret_cast<const f32x2 *>(g.D + (long)pid[u] * g.ldd + col);
+                if (PAIR) pv2[u] = *reinterpret_cast<const f32x2 *>(g.D + (long)pid2[u] * g.ldd + col);
+                pwl[u] = pw[u];                                  // (the ids and weights of the NEXT block are fetched before these values are stored)
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const float *row = g.D + (long)id_nx[u] * g.ldd;
@@ -146,6 +185,29 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         }
     };
     auto store_rows = [&](int buf) {
+        if (PRE) {
+            bf16x4 e[3][2];                                      // [plane][column of the pair]: the four K rows of this wave
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    float v = pv[u][cc];
+                    if (PAIR) v -= pv2[u][cc];                   // Dist = Desc1 - Desc2, src/comp-uprjdists.cpp:327
+                    v *= pwl[u];                                 // w_k x_k for the A operand (w = 1 for B); same rounding as the fp32 path
+                    const __bf16 h = (__bf16)v;
+                    const float r1 = v - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    e[0][cc][u] = h; e[1][cc][u] = m; e[2][cc][u] = (__bf16)(r1 - (float)m);
+                }
+            bf16x4 *base = p_op == 0 ? &lds.sp.A[buf][0][0][0] : &lds.sp.B[buf][0][0][0];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                bf16x4 *dst = base + ((pl * 4 + p_kq) * TB + 2 * p_c2);
+                dst[0] = e[pl][0];
+                dst[1] = e[pl][1];
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             *reinterpret_cast<f32x4 *>(&lds.st.A[buf][rbase + 16 * u][c4 * 4]) = ra[u];
@@ -181,7 +243,29 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         const int buf = kt & 1;
         if (kt + 1 < nk) load_rows();
         if (kt + 2 < nk) load_ids(kt + 2);
-        if (BF16) {
+        if (PRE) {
+            // fragment of lane (lr, lk): K rows 8 lk .. 8 lk + 7 of the block = entries [2 lk] and [2 lk + 1] of its column
+            auto frag = [&](const bf16x4 *plane, int col) {
+                const bf16x4 lo4 = plane[(2 * lk) * TB + col], hi4 = plane[(2 * lk + 1) * TB + col];
+                bf16x8 f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { f[j] = lo4[j]; f[4 + j] = hi4[j]; }
+                return f;
+            };
+            const int bcol = wn * 32 + lr;
+            const bf16x8 bh = frag(&lds.sp.B[buf][0][0][0], bcol), bm = frag(&lds.sp.B[buf][1][0][0], bcol), bl = frag(&lds.sp.B[buf][2][0][0], bcol);
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int acol = wm * 64 + 32 * a + lr;
+                const bf16x8 ah = frag(&lds.sp.A[buf][0][0][0], acol), am = frag(&lds.sp.A[buf][1][0][0], acol), al = frag(&lds.sp.A[buf][2][0][0], acol);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[a], 0, 0, 0);
+            }
+        } else if (BF16 == 1) {
 #pragma unroll
             for (int ks = 0; ks < KB / 16; ks++) {
                 bf16x8 a0, a1, b0;
@@ -385,15 +469,25 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     }
 #define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
 #define DLCO_SYRK_LAUNCH_PK(P, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, H, true>), dim3(ntiles), dim3(NT8), 0, s, g)
+    // precision of the products: 3 (default) = three-way split bf16, fp32-level results at 3/8 of the fp32 matrix time
+    // (0.189 against 0.219 ms per launch at K = 305: the launch is then spread over matrix time, conversions, LDS and its
+    // HBM phase instead of waiting on the fp32 MFMA pipe); 0 = fp32 MFMA, a k-ordered fmaf chain (DLCO_SYRK_FP32=1);
+    // 1 = operands rounded to bf16 once (cfg.grad_bf16, the configs[4] variant)
+    static const bool exact_fp32 = std::getenv("DLCO_SYRK_FP32") != nullptr;
+    const int prec = bf16 ? 1 : (exact_fp32 ? 0 : 3);
     if (packed) {
-        if (bf16) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, true); else DLCO_SYRK_LAUNCH_PK(false, true); }
-        else { if (ids2) DLCO_SYRK_LAUNCH_PK(true, false); else DLCO_SYRK_LAUNCH_PK(false, false); }
-    } else if (bf16) {
-        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, true); else DLCO_SYRK_LAUNCH(false, true, true); }
-        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, true); else DLCO_SYRK_LAUNCH(false, false, true); }
+        if (prec == 1) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 1); else DLCO_SYRK_LAUNCH_PK(false, 1); }
+        else if (prec == 3) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 3); else DLCO_SYRK_LAUNCH_PK(false, 3); }
+        else { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 0); else DLCO_SYRK_LAUNCH_PK(false, 0); }
+    } else if (prec == 1) {
+        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 1); else DLCO_SYRK_LAUNCH(false, true, 1); }
+        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 1); else DLCO_SYRK_LAUNCH(false, false, 1); }
+    } else if (prec == 3) {
+        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 3); else DLCO_SYRK_LAUNCH(false, true, 3); }
+        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 3); else DLCO_SYRK_LAUNCH(false, false, 3); }
     } else {
-        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, false); else DLCO_SYRK_LAUNCH(false, true, false); }
-        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, false); else DLCO_SYRK_LAUNCH(false, false, false); }
+        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 0); else DLCO_SYRK_LAUNCH(false, true, 0); }
+        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 0); else DLCO_SYRK_LAUNCH(false, false, 0); }
     }
 #undef DLCO_SYRK_LAUNCH_PK
 #undef DLCO_SYRK_LAUNCH

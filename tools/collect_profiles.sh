@@ -5,21 +5,21 @@
 #   3. the default bench line with its cpu_baseline leg
 # Outputs land in gpurun_out/profiles_new/; copy what is wanted into profiles/.
 set -e
-R=${DLCO_ROUND:-r2}
+R=${DLCO_ROUND:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 > $OUT/stats_bench.json 2> $OUT/stats.log
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/${R}_bench_kernel_stats_timed.csv > $OUT/${R}_bench_step_breakdown.txt
 rm -rf $OUT/stats
 # the same trace for the rank ~128 workload (BASELINE configs[2])
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $ROOT/bench.py --config c3 --no-cpu-baseline > $OUT/${R}_bench_c3.json 2> $OUT/stats_c3.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $ROOT/bench.py --config c3 --no-cpu-baseline --reference-iters 0 > $OUT/stats_c3_bench.json 2> $OUT/stats_c3.log
 python3 $ROOT/tools/trace_breakdown.py $OUT/stats_c3 200 $OUT/${R}_bench_c3_kernel_stats_timed.csv > $OUT/${R}_bench_c3_step_breakdown.txt
 rm -rf $OUT/stats_c3
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
   DLCO_ROUND=$R python3 - $OUT/pmc_$c $c $OUT <<'PY'
 import csv, glob, sys
 d, c, out = sys.argv[1:4]
@@ -34,6 +34,10 @@ with open("%s/%s_pmc_%s_syrk.csv" % (out, os.environ.get("DLCO_ROUND", "r2"), c.
 mean = sum(float(r["Counter_Value"]) for r in rows) / max(len(rows), 1)
 print(c, "mean per launch:", mean, "over", len(rows))
 open("%s/pmc_mean_%s.txt" % (out, c), "w").write("%r %d\n" % (mean, len(rows)))
+# the tracker's product kernels on the packed dual average (two-way filter pass, three-way Rayleigh-Ritz pass)
+for tag, key in (("sym2", "skinny_sym_kernel<3, 2>"), ("sym3", "skinny_sym_kernel<3, 3>")):
+    rs = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if key in r["Kernel_Name"] and r["Counter_Name"] == c][-40:]
+    open("%s/pmc_mean_%s_%s.txt" % (out, c, tag), "w").write("%r %d\n" % (sum(rs) / max(len(rs), 1), len(rs)))
 PY
   rm -rf $OUT/pmc_$c
 done
@@ -53,9 +57,25 @@ js = {"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -
       "note": "values are per launch, mean of the last %s launches of the SYRK in the run (mean K ~ %s rows); FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X guide, HBM section): reads are doubled" % (nf, K),
       "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
       "hbm_bytes_per_launch_raw": (f + w) * 1024.0, "hbm_bytes_per_launch_corrected": (2 * f + w) * 1024.0,
-      "algorithmic_bytes_per_launch": 8 * F * F + 4 * (K or 0) * F}
+      "algorithmic_bytes_per_launch": 8 * F * F + 4 * (K or 0) * F,
+      "packed_layout_bytes_per_launch": 8 * (F // 128) * (F // 128 + 1) // 2 * 128 * 128 + 4 * (K or 0) * F,
+      "layout_note": "round 3: the single-rank trainer keeps dfAvg as its packed upper 128 x 128 tiles (2080 tiles, 136 MB): the SYRK reads and "
+                     "writes each tile once and stores no mirror, so its own bytes are packed_layout_bytes_per_launch; algorithmic_bytes_per_launch "
+                     "is SURVEY 8(d)'s dense figure (8 F^2 + 4 K F)"}
+prod = {}
+for tag, what in (("sym2", "two-way split filter pass, 96 rows"), ("sym3", "three-way split Rayleigh-Ritz pass, 96 rows")):
+    try:
+        ff, _ = open(out + "/pmc_mean_FETCH_SIZE_%s.txt" % tag).read().split()
+        ww, n = open(out + "/pmc_mean_WRITE_SIZE_%s.txt" % tag).read().split()
+        prod[tag] = {"kernel": "skinny_sym_kernel (%s)" % what, "FETCH_SIZE_KiB_per_launch": float(ff), "WRITE_SIZE_KiB_per_launch": float(ww),
+                     "hbm_bytes_per_launch_corrected": (2 * float(ff) + float(ww)) * 1024.0, "launches_sampled": int(n),
+                     "packed_matrix_bytes": (F // 128) * (F // 128 + 1) // 2 * 128 * 128 * 4, "full_matrix_bytes": 4 * F * F}
+    except Exception as e:
+        prod[tag] = {"error": str(e)}
+js["tracker_product_on_packed_tiles"] = prod
 json.dump(js, open("%s/%s_pmc_syrk.json" % (out, R), "w"), indent=1)
 print(json.dumps(js))
 PY
 cd $ROOT && python3 bench.py > $OUT/${R}_bench_default.json 2> $OUT/bench_default.log
+python3 bench.py --config c3 --cpu-steps 2 > $OUT/${R}_bench_c3.json 2> $OUT/bench_c3.log
 tail -c 600 $OUT/${R}_bench_default.json
