@@ -247,12 +247,12 @@ void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, fl
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
                  hipStream_t s, float lam_cut = -3.0e38f);
 size_t jacobi_work_floats(int n);
-// CholQR building block for panels of <= 128 rows: factors the panel's Gram matrix M = L L^T
+// CholQR building block for panels of <= 160 rows: factors the panel's Gram matrix M = L L^T
 // (only its lower triangle is read) and returns Linv = L^-1 [n][ldl] (lower triangular, upper
 // part zero), so that the orthonormal rows are the plain product Linv * Z.  A row whose pivot
 // falls below rel_thresh * M_jj lies in the span of the rows before it: dead[j] = 1 and row j of
 // Linv is zero.
-constexpr int CHOL_INV_MAX_N = 128;
+constexpr int CHOL_INV_MAX_N = 160;
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s);
 // row norms of (Y - theta_i X) and of X
 // n floats -> pinned host memory, then *flag_host = seq with system-scope release (the host polls flag_host)

@@ -220,48 +220,55 @@ __global__ __launch_bounds__(CI_T) void chol_inv_kernel(const float *M, long ldm
 // tx + 32 c of [M | I]); LDS only carries the block's rows, columns, T, P and F.  Four barriers per
 // block of 32 pivots.  Same result up to rounding (the multipliers are a[j] * rcp(d) instead of a[j] / d;
 // CholQR2's second pass absorbs that), same dead-row rule, same fast path for M = I + E.
+// NBM = blocks of 32 rows the kernel is built for: 4 (n <= 128) or 5 (n <= 160: the block of the rank ~128 workload in ONE
+// orthonormalisation panel instead of two panels with a Gram-Schmidt step between them; 50 registers of matrix per thread).
 constexpr int C2_T = 1024;
-constexpr int C2_PLD = 256 + 4;            // row stride of the P images (floats)
-constexpr size_t C2_LDS_FLOATS = (size_t)2 * 32 * 33 + 2 * 32 * C2_PLD + 2 * 128 * 33 + 128 * 3 + 64 + 32 * 64;
+__host__ __device__ constexpr int c2_pld(int nbm) { return 64 * nbm + 4; }            // row stride of the P images (floats)
+__host__ __device__ constexpr size_t c2_lds_floats(int nbm)
+{
+    return (size_t)2 * 32 * 33 + 2 * 32 * c2_pld(nbm) + 2 * 32 * nbm * 33 + 32 * nbm * 3 + 64 + 2 * nbm * nbm * 64;
+}
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+template <int NBM>
 __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl,
                                                          int *dead)
 {
     extern __shared__ __attribute__((aligned(16))) float c2[];
     float (*Dblk)[33] = reinterpret_cast<float (*)[33]>(c2);
     float (*Tblk)[33] = reinterpret_cast<float (*)[33]>(c2 + 32 * 33);
+    constexpr int C2_PLD = c2_pld(NBM), NR = 32 * NBM;         // NR: rows / columns the registers cover
     float (*Praw)[C2_PLD] = reinterpret_cast<float (*)[C2_PLD]>(c2 + 2 * 32 * 33);
     float (*Pbuf)[C2_PLD] = reinterpret_cast<float (*)[C2_PLD]>(c2 + 2 * 32 * 33 + 32 * C2_PLD);
     float (*Acol)[33] = reinterpret_cast<float (*)[33]>(c2 + 2 * 32 * 33 + 2 * 32 * C2_PLD);
-    float (*Fbuf)[33] = reinterpret_cast<float (*)[33]>(c2 + 2 * 32 * 33 + 2 * 32 * C2_PLD + 128 * 33);
-    float *diag0 = c2 + 2 * 32 * 33 + 2 * 32 * C2_PLD + 2 * 128 * 33;
-    float *dpiv = diag0 + 128;
-    int *deadf = reinterpret_cast<int *>(dpiv + 128);
-    float *dinv = dpiv + 256;                                  // [32] of the current block, then scratch [16]
-    float *stash = dinv + 64;                                  // [32][64]: the eliminating wave's own entries
+    float (*Fbuf)[33] = reinterpret_cast<float (*)[33]>(c2 + 2 * 32 * 33 + 2 * 32 * C2_PLD + NR * 33);
+    float *diag0 = c2 + 2 * 32 * 33 + 2 * 32 * C2_PLD + 2 * NR * 33;
+    float *dpiv = diag0 + NR;
+    int *deadf = reinterpret_cast<int *>(dpiv + NR);
+    float *dinv = dpiv + 2 * NR;                               // [32] of the current block, then scratch [16]
+    float *stash = dinv + 64;                                  // [2 NBM^2][64]: the eliminating wave's own entries
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const int nb = (n + 31) >> 5;
 
-    // reg[r][c]: row 32r + ty; c < 4: column 32c + tx of M, c >= 4: column 32(c-4) + tx of the identity
-    float reg[4][8];
+    // reg[r][c]: row 32r + ty; c < NBM: column 32c + tx of M, c >= NBM: column 32(c-NBM) + tx of the identity
+    float reg[NBM][2 * NBM];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < NBM; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NBM; c++) {
             const int i = 32 * r + ty, k = 32 * c + tx;
             reg[r][c] = (i < n && k < n) ? M[(long)max(i, k) * ldm + min(i, k)] : ((i == k) ? 1.f : 0.f);
-            reg[r][4 + c] = (i == k) ? 1.f : 0.f;
+            reg[r][NBM + c] = (i == k) ? 1.f : 0.f;
         }
-    if (t < 128) { diag0[t] = t < n ? M[(long)t * ldm + t] : 1.f; deadf[t] = 0; dpiv[t] = 1.f; }
+    if (t < NR) { diag0[t] = t < n ? M[(long)t * ldm + t] : 1.f; deadf[t] = 0; dpiv[t] = 1.f; }
     // Fast path (second pass of CholQR2): M = I + E with |E|_F^2 <= 1e-6 -> M^-1/2 = I - E/2 (see chol_inv_kernel)
     {
         float e2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < NBM; r++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const float e = reg[r][c] - ((32 * r + ty == 32 * c + tx) ? 1.f : 0.f); e2 += e * e; }
+            for (int c = 0; c < NBM; c++) { const float e = reg[r][c] - ((32 * r + ty == 32 * c + tx) ? 1.f : 0.f); e2 += e * e; }
         e2 = wsum(e2);
         if ((t & 63) == 0) dinv[32 + (t >> 6)] = e2;
     }
@@ -271,9 +278,9 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
         for (int w = 0; w < C2_T / 64; w++) tot += dinv[32 + w];
         if (tot <= 1e-6f) {                                   // workgroup-uniform (false for NaN)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < NBM; r++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
+                for (int c = 0; c < NBM; c++) {
                     const int i = 32 * r + ty, k = 32 * c + tx;
                     if (i < n && k < n) Linv[(long)i * ldl + k] = ((i == k) ? 1.5f : 0.f) - 0.5f * reg[r][c];
                 }
@@ -294,9 +301,9 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
                 // this wave's own matrix entries wait in LDS meanwhile: the elimination needs 64 registers
                 // per lane and must not spill (a spilled register costs a trip to memory per pivot)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < NBM; r++)
 #pragma unroll
-                    for (int c = 0; c < 8; c++) stash[(r * 8 + c) * 64 + t] = reg[r][c];
+                    for (int c = 0; c < 2 * NBM; c++) stash[(r * 2 * NBM + c) * 64 + t] = reg[r][c];
                 const int i = t & 31;
                 float a[32], x[32];
 #pragma unroll
@@ -320,42 +327,42 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
                     for (int k = 0; k < 32; k++) Tblk[i][k] = x[k];
                 }
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < NBM; r++)
 #pragma unroll
-                    for (int c = 0; c < 8; c++) reg[r][c] = stash[(r * 8 + c) * 64 + t];
+                    for (int c = 0; c < 2 * NBM; c++) reg[r][c] = stash[(r * 2 * NBM + c) * 64 + t];
             }
             // ---- 3a. the block's rows (columns still needed) and the block's columns of the rows below ---
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < NBM; c++) {
                 if (c > kb && c < nb) Praw[ty][32 * c + tx] = reg[kb][c];            // M part right of the block
-                if (c <= kb) Praw[ty][128 + 32 * c + tx] = reg[kb][4 + c];           // identity part up to the block
+                if (c <= kb) Praw[ty][NR + 32 * c + tx] = reg[kb][NBM + c];           // identity part up to the block
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < NBM; r++)
                 if (r > kb && r < nb) Acol[32 * r + ty][tx] = reg[r][kb];
             __syncthreads();
             // ---- 3b. P = T * rows (this thread's row of the block), F = (A[:,K] T^T) / d --------------------
             {
-                float pacc[8];
+                float pacc[2 * NBM];
 #pragma unroll
-                for (int c = 0; c < 8; c++) pacc[c] = 0.f;
+                for (int c = 0; c < 2 * NBM; c++) pacc[c] = 0.f;
 #pragma unroll 2
                 for (int j = 0; j < 32; j++) {
                     const float tj = Tblk[ty][j];                     // zero for j > ty
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NBM; c++) {
                         if (c > kb && c < nb) pacc[c] += tj * Praw[j][32 * c + tx];
-                        if (c <= kb) pacc[4 + c] += tj * Praw[j][128 + 32 * c + tx];
+                        if (c <= kb) pacc[NBM + c] += tj * Praw[j][NR + 32 * c + tx];
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
+                for (int c = 0; c < NBM; c++) {
                     if (c > kb && c < nb) { reg[kb][c] = pacc[c]; Pbuf[ty][32 * c + tx] = pacc[c]; }
-                    if (c <= kb) { reg[kb][4 + c] = pacc[4 + c]; Pbuf[ty][128 + 32 * c + tx] = pacc[4 + c]; }
+                    if (c <= kb) { reg[kb][NBM + c] = pacc[NBM + c]; Pbuf[ty][NR + 32 * c + tx] = pacc[NBM + c]; }
                 }
                 const float di = dinv[tx];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < NBM; r++) {
                     if (r > kb && r < nb) {
                         float facc = 0.f;
 #pragma unroll 4
@@ -369,21 +376,21 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
             if (kb + 1 < nb) {
 #pragma unroll 2
                 for (int j = 0; j < 32; j++) {
-                    float fr[4], pc[8];
+                    float fr[NBM], pc[2 * NBM];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) fr[r] = (r > kb && r < nb) ? Fbuf[32 * r + ty][j] : 0.f;
+                    for (int r = 0; r < NBM; r++) fr[r] = (r > kb && r < nb) ? Fbuf[32 * r + ty][j] : 0.f;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NBM; c++) {
                         pc[c] = (c > kb && c < nb) ? Pbuf[j][32 * c + tx] : 0.f;
-                        pc[4 + c] = (c <= kb) ? Pbuf[j][128 + 32 * c + tx] : 0.f;
+                        pc[NBM + c] = (c <= kb) ? Pbuf[j][NR + 32 * c + tx] : 0.f;
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
+                    for (int r = 0; r < NBM; r++) {
                         if (r > kb) {
 #pragma unroll
-                            for (int c = 0; c < 4; c++) {
+                            for (int c = 0; c < NBM; c++) {
                                 if (c > kb) reg[r][c] -= fr[r] * pc[c];
-                                if (c <= kb) reg[r][4 + c] -= fr[r] * pc[4 + c];
+                                if (c <= kb) reg[r][NBM + c] -= fr[r] * pc[NBM + c];
                             }
                         }
                     }
@@ -395,17 +402,18 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
     block(std::integral_constant<int, 1>{});
     block(std::integral_constant<int, 2>{});
     block(std::integral_constant<int, 3>{});
+    if (NBM > 4) block(std::integral_constant<int, NBM - 1>{});
     __syncthreads();
     // Linv = D^-1/2 U^-1 (lower triangular); dead rows and the padding are zero
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < NBM; r++) {
         const int i = 32 * r + ty;
         if (i < n) {
             const float sc = deadf[i] ? 0.f : rsqrtf(dpiv[i]);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < NBM; c++) {
                 const int k = 32 * c + tx;
-                if (k < n) Linv[(long)i * ldl + k] = (k <= i) ? reg[r][4 + c] * sc : 0.f;
+                if (k < n) Linv[(long)i * ldl + k] = (k <= i) ? reg[r][NBM + c] * sc : 0.f;
             }
         }
     }
@@ -414,21 +422,25 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
 
 }  // namespace
 
+template <int NBM>
+static void launch_chol_inv2(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_inv2_kernel<NBM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(c2_lds_floats(NBM) * sizeof(float))));
+        attr = true;
+    }
+    hipLaunchKernelGGL(chol_inv2_kernel<NBM>, dim3(1), dim3(C2_T), c2_lds_floats(NBM) * sizeof(float), s, M, ldm, n, rel_thresh, Linv, ldl, dead);
+}
+
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
 {
     DLCO_CHECK(n >= 1 && n <= CHOL_INV_MAX_N, -2, "chol_inverse128: n out of range");
     static const bool use_v1 = std::getenv("DLCO_CHOL_V1") != nullptr;
-    if (use_v1) {
-        hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(CI_T), 0, s, M, ldm, n, rel_thresh, Linv, ldl, dead);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_inv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(C2_LDS_FLOATS * sizeof(float))));
-            attr = true;
-        }
-        hipLaunchKernelGGL(chol_inv2_kernel, dim3(1), dim3(C2_T), C2_LDS_FLOATS * sizeof(float), s, M, ldm, n, rel_thresh, Linv, ldl, dead);
-    }
+    if (use_v1 && n <= 128) hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(CI_T), 0, s, M, ldm, n, rel_thresh, Linv, ldl, dead);
+    else if (n <= 128) launch_chol_inv2<4>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
+    else launch_chol_inv2<5>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
     DLCO_HIP(hipGetLastError());
 }
 
