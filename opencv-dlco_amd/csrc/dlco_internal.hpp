@@ -132,6 +132,8 @@ struct GemmArgs {
     bool upper_only = false;            // M==N: compute tiles with j-block >= i-block, mirror the rest
     bool raw_slab = false;              // keep the [split][M][N] partials in `slab`, skip the reduce (C unused)
     int *split_out = nullptr;           // receives the number of K slices actually used
+    const float *B2 = nullptr;          // twin product in the same launch: C2 = alpha * A * B2 (+ the same epilogue terms), B2 laid
+    float *C2 = nullptr;                // out like B; needs split_k == 1
 };
 
 void gemm_f32(const GemmArgs &a, hipStream_t s);
@@ -237,10 +239,11 @@ void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, fl
                 float noise, float jitter, hipStream_t s);
 
 // ---------------------------------------------------------------------------
-// small dense eigen problems on one workgroup (kernels_eig.hip)
+// small dense eigen problems (kernels_jacobi.hip, kernels_eig.hip)
 // ---------------------------------------------------------------------------
-// One-sided Jacobi on a symmetric n x n matrix T (ld = ldt).  Output: evals[n] descending,
-// V[n][ldv] with COLUMN j = eigenvector j.  work: >= 2*n*n + 4*n floats.  n <= 1024.
+// One-sided Jacobi on a symmetric n x n matrix T (ld = ldt; symmetric up to rounding: for n <= 160 the rows of T are
+// taken as the columns of the work image without averaging).  Output: evals[n] descending, V[n][ldv] with ROW j =
+// eigenvector j.  work: >= jacobi_work_floats(n) floats.  n <= 4096.
 // lam_cut: a pair of columns whose eigenvalue estimates are BOTH below it is still rotated but does not
 // keep the sweeps going (the tracker's guard vectors: only their span matters, and the caller checks the
 // residuals of the pairs it keeps); the default counts every pair.
@@ -258,6 +261,9 @@ void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *L
 // n floats -> pinned host memory, then *flag_host = seq with system-scope release (the host polls flag_host)
 void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
                    const int *extra_dev = nullptr, int *extra_host = nullptr);   // extra: one device int copied along
+void residual_norms_publish(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res, unsigned *ticket,
+                            const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
+                            const int *extra_dev = nullptr, int *extra_host = nullptr);
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
 void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);

@@ -27,6 +27,7 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     evals_.p = ritz_block_.p;
     res_.p = ritz_block_.p + (cap_ + 8);
     sweeps_dev_ = reinterpret_cast<int *>(ritz_block_.p + 2 * (cap_ + 8));
+    DLCO_HIP(hipMemsetAsync(sweeps_dev_, 0, 8 * sizeof(int), s_));   // [0] Jacobi sweeps, [4] ticket of the residual / publish kernel
     scale_.alloc(cap_ + 8);
     srcrow_.alloc(cap_ + 8);
     jwork_.alloc(jacobi_work_floats(cap_));
@@ -220,14 +221,15 @@ void EigTracker::gram(const float *X, const float *Y, int rows, float *T)
     gemm_f32(g, s_);
 }
 
-// out[k_out][F] = C^T X with C [k_in][ldc] holding the coefficient vectors in its columns
-void EigTracker::rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out)
+// out[k_out][F] = C X with C [k_out][ldc] holding the coefficient vectors in its rows (jacobi_eigh's layout)
+void EigTracker::rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out, const float *X2, float *out2)
 {
     GemmArgs g;
     g.M = k_out; g.N = F_; g.K = k_in;
-    g.A.p = C; g.A.ld = ldc; g.A.kmajor = true;
+    g.A.p = C; g.A.ld = ldc; g.A.kmajor = false;
     g.B.p = X; g.B.ld = F_; g.B.kmajor = true;
     g.C = out; g.ldc = F_;
+    g.B2 = X2; g.C2 = out2;                                          // the Ritz step rotates Q and Y = Q H with one launch
     gemm_f32(g, s_);
 }
 
@@ -470,20 +472,21 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_, lam_cut);
         if (prof_) prof_->end(PROF_JACOBI);
         float *Qn = pick({Qo, Yb});
-        rotate(Vm_.p, cap_, m_, m_, Qo, Qn);
         float *Yn = pick({Qo, Yb, Qn});
-        rotate(Vm_.p, cap_, m_, m_, Yb, Yn);
+        rotate(Vm_.p, cap_, m_, m_, Qo, Qn, Yb, Yn);
         Q_ = Qn; Y_ = Yn;
         y_ok_ = true;                                                // Y_ = Q_ H for the current H
-        residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
         const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
+        if (!poll_readback_) residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
         if (poll_readback_) {
             // the block is written into pinned memory by a kernel that raises a sequence number last; polling it
             // costs a few microseconds where copy + hipStreamSynchronize cost tens (one read-back per pass)
             unsigned *flag = reinterpret_cast<unsigned *>(pin_ + pin_floats_ - 16);
             const unsigned seq = ++publish_seq_;
             int *extra_host = reinterpret_cast<int *>(pin_ + pin_floats_ - 32);
-            publish_block(ritz_block_.p, pin_, (int)blk, flag, seq, s_, extra_dev_, extra_host);
+            // (the residual kernel's last workgroup publishes: one launch)
+            residual_norms_publish(Q_, Y_, F_, evals_.p, m_, F_, res_.p, reinterpret_cast<unsigned *>(sweeps_dev_ + 4), ritz_block_.p, pin_,
+                                   (int)blk, flag, seq, s_, extra_dev_, extra_host);
             const auto t0 = std::chrono::steady_clock::now();
             bool seen = false;
             for (long spins = 0;; spins++) {

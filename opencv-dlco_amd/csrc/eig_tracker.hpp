@@ -61,7 +61,7 @@ private:
     void gram(const float *X, const float *Y, int rows, float *T);
     void gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T);
     void project_out(float *Wp, int np, const float *Q, int kept);
-    void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out);
+    void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out, const float *X2 = nullptr, float *out2 = nullptr);
     int orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends);
     int drop_dead_rows();
     void refresh_lower_bound(const float *G, int iters, float theta_top);

@@ -456,6 +456,59 @@ __global__ __launch_bounds__(256) void publish_block_kernel(const float *src, fl
     if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// residual_kernel and publish_block_kernel in one launch: the workgroup that finishes LAST (a ticket counter, left at zero
+// again) copies the block - which holds the residuals the other workgroups have just written, hence the agent-scope
+// release / acquire pair around the ticket and the agent-scope loads - and raises the sequence number.
+__global__ __launch_bounds__(256) void residual_publish_kernel(const float *X, const float *Y, long ld, const float *theta, int m, int F,
+                                                               float *res, unsigned *ticket, const float *src, float *dst_host, int n,
+                                                               unsigned *flag_host, unsigned seq, const int *extra_dev, int *extra_host)
+{
+    __shared__ float part[4];
+    __shared__ int last;
+    const int i = blockIdx.x;
+    const float th = theta[i];
+    float s = 0.f;
+    if ((F & 3) == 0 && (ld & 3) == 0) {
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(Y + (long)i * ld), *x4 = reinterpret_cast<const f32x4 *>(X + (long)i * ld);
+        for (int f = threadIdx.x; f < F / 4; f += blockDim.x) {
+            const f32x4 d = y4[f] - th * x4[f];
+            s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    } else {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) {
+            const float d = Y[(long)i * ld + f] - th * X[(long)i * ld + f];
+            s += d * d;
+        }
+    }
+    s = wsum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(res + i, sqrtf(part[0] + part[1] + part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int k = threadIdx.x; k < n; k += 256) dst_host[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (extra_dev && threadIdx.x == 0) *extra_host = __hip_atomic_load(extra_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void residual_norms_publish(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res, unsigned *ticket,
+                            const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
+                            const int *extra_dev, int *extra_host)
+{
+    DLCO_CHECK(m > 0, -2, "residual_norms_publish: empty block");
+    hipLaunchKernelGGL(residual_publish_kernel, dim3(m), dim3(256), 0, s, X, Y, ld, theta, m, F, res, ticket, src, dst_host, n, flag_host,
+                       seq, extra_dev, extra_host);
+    DLCO_HIP(hipGetLastError());
+}
+
 void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s, const int *extra_dev,
                    int *extra_host)
 {

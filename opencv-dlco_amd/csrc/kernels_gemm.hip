@@ -55,6 +55,8 @@ struct GemmDev {
     int k_chunk;      // K range per blockIdx.z
     float *slab;      // != nullptr: write raw partials to slab[z][M][N]
     int upper_only;
+    const float *B2;  // != nullptr: a second product with the same A in the same launch, blockIdx.z == 1: C2 = A * B2 (no K split)
+    float *C2;
 };
 
 // Stage one BK x BT tile of an operand into LDS (k-major image [BK][BT+PAD]).
@@ -126,7 +128,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmDev g)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    int kbeg = blockIdx.z * g.k_chunk;
+    int kz = blockIdx.z;
+    if (g.B2) {
+        if (kz == 1) { g.B.p = g.B2; g.C = g.C2; }
+        kz = 0;
+    }
+    int kbeg = kz * g.k_chunk;
     int kend = min(g.K, kbeg + g.k_chunk);
     if (g.k_dev) kend = min(kend, *g.k_dev);
 
@@ -492,6 +499,11 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
         g.slab = a.slab;
     }
     if (a.split_out) *a.split_out = split;
+    g.B2 = a.B2; g.C2 = a.C2;
+    if (a.B2) {
+        DLCO_CHECK(a.C2 && split == 1 && !a.raw_slab && !a.upper_only, -2, "gemm_f32: a twin product needs C2 and no K split");
+        split = 2;                                                 // grid z = the two products
+    }
     // tile choice: the small dimension decides; a launch that would leave most of the 256 CUs
     // without a workgroup takes 64-wide tiles instead (the tracker's m x F x m products)
     bool small_m = a.M <= 64, small_n = a.N <= 64;
@@ -516,7 +528,7 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
         launch<2, 2>(g, a.A.kmajor, a.B.kmajor, grid, s);
     }
     DLCO_HIP(hipGetLastError());
-    if (split > 1 && !a.raw_slab)
+    if (split > 1 && !a.raw_slab && !a.B2)
         splitk_reduce_f32(a.slab, split, a.M, a.N, a.C, a.ldc, a.alpha, a.beta, a.E1, a.b1, a.E2, a.b2, s);
 }
 

@@ -53,13 +53,8 @@ struct SyrkDev {
     unsigned long long *trace;    // developer aid (DLCO_SYRK_TRACE): 6 words per workgroup, see syrk_rda_f32
 };
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 union SyrkLds {
     struct { float A[2][KB][LD]; float B[2][KB][LD]; } st;    // 67,584 B
-    // three-way split mode: per stage and operand three bf16 planes (hi, mid, lo) of a 16-deep K block, entry
-    // [k / 4][column] = the four consecutive k of that column (8 bytes): an MFMA fragment is two 8-byte reads
-    struct { bf16x4 A[2][3][4][TB]; bf16x4 B[2][3][4][TB]; } sp;   // 49,152 B
     float T[TB][TLD];                                          // 66,048 B
 };
 
@@ -113,12 +108,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
     const int wm = wave >> 2, wn = wave & 3;                  // rows wm*64.., columns wn*32.. of the tile
     const int lr = lane & 31, lk = lane >> 5;
 
-    // BF16 == 3: fp32 results from the bf16 matrix cores.  Every staged value is split three ways, x = hi + mid + lo (all
-    // 24 mantissa bits), ONCE, by the thread that gathers it, and stored as three bf16 planes; the K loop then forms the
-    // six products down to 2^-16 (hh, hm, mh, mm, hl, lh; smallest first, fp32 accumulation) - 6/16 of the fp32-MFMA
-    // time, no conversion work in front of the MFMAs, 16-deep K blocks (49 KB of LDS: still two workgroups per CU).
-    constexpr bool PRE = BF16 == 3;
-    constexpr int KD = PRE ? 16 : KB;
+    constexpr int KD = KB;
     const int kact = min(*g.k_dev, g.kmax);
     const int nk = (kact + KD - 1) / KD;
 
@@ -133,24 +123,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
     int32_t id_nx[2], id2_nx[2];
     float w_nx[2];
     f32x4 ra[2], rb[2];
-    // loader mapping (three-way split): wave -> (operand, group of four K rows), lane -> a pair of columns; the four
-    // rows of a wave are wave-uniform, the lane loads 8 bytes of each
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int p_op = wave >> 2, p_kq = wave & 3, p_c2 = lane;
-    int32_t pid[4], pid2[4];
-    float pw[4], pwl[4];                                      // weights of the rows whose ids / whose values are held
-    f32x2 pv[4], pv2[4];
     auto load_ids = [&](int kt) {
-        if (PRE) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = kt * KD + p_kq * 4 + u;
-                pid[u] = g.ids[k];
-                if (PAIR) pid2[u] = g.ids2[k];
-                pw[u] = p_op == 0 ? g.w[k] : 1.0f;
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int k = kt * KB + rbase + 16 * u;
@@ -160,16 +133,6 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         }
     };
     auto load_rows = [&]() {
-        if (PRE) {
-            const int col = (p_op == 0 ? i0 : j0) + 2 * p_c2;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                pv[u] = *reinterpret_cast<const f32x2 *>(g.D + (long)pid[u] * g.ldd + col);
-                if (PAIR) pv2[u] = *reinterpret_cast<const f32x2 *>(g.D + (long)pid2[u] * g.ldd + col);
-                pwl[u] = pw[u];                                  // (the ids and weights of the NEXT block are fetched before these values are stored)
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const float *row = g.D + (long)id_nx[u] * g.ldd;
@@ -185,29 +148,6 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         }
     };
     auto store_rows = [&](int buf) {
-        if (PRE) {
-            bf16x4 e[3][2];                                      // [plane][column of the pair]: the four K rows of this wave
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-                for (int cc = 0; cc < 2; cc++) {
-                    float v = pv[u][cc];
-                    if (PAIR) v -= pv2[u][cc];                   // Dist = Desc1 - Desc2, src/comp-uprjdists.cpp:327
-                    v *= pwl[u];                                 // w_k x_k for the A operand (w = 1 for B); same rounding as the fp32 path
-                    const __bf16 h = (__bf16)v;
-                    const float r1 = v - (float)h;
-                    const __bf16 m = (__bf16)r1;
-                    e[0][cc][u] = h; e[1][cc][u] = m; e[2][cc][u] = (__bf16)(r1 - (float)m);
-                }
-            bf16x4 *base = p_op == 0 ? &lds.sp.A[buf][0][0][0] : &lds.sp.B[buf][0][0][0];
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                bf16x4 *dst = base + ((pl * 4 + p_kq) * TB + 2 * p_c2);
-                dst[0] = e[pl][0];
-                dst[1] = e[pl][1];
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             *reinterpret_cast<f32x4 *>(&lds.st.A[buf][rbase + 16 * u][c4 * 4]) = ra[u];
@@ -243,29 +183,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         const int buf = kt & 1;
         if (kt + 1 < nk) load_rows();
         if (kt + 2 < nk) load_ids(kt + 2);
-        if (PRE) {
-            // fragment of lane (lr, lk): K rows 8 lk .. 8 lk + 7 of the block = entries [2 lk] and [2 lk + 1] of its column
-            auto frag = [&](const bf16x4 *plane, int col) {
-                const bf16x4 lo4 = plane[(2 * lk) * TB + col], hi4 = plane[(2 * lk + 1) * TB + col];
-                bf16x8 f;
-#pragma unroll
-                for (int j = 0; j < 4; j++) { f[j] = lo4[j]; f[4 + j] = hi4[j]; }
-                return f;
-            };
-            const int bcol = wn * 32 + lr;
-            const bf16x8 bh = frag(&lds.sp.B[buf][0][0][0], bcol), bm = frag(&lds.sp.B[buf][1][0][0], bcol), bl = frag(&lds.sp.B[buf][2][0][0], bcol);
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int acol = wm * 64 + 32 * a + lr;
-                const bf16x8 ah = frag(&lds.sp.A[buf][0][0][0], acol), am = frag(&lds.sp.A[buf][1][0][0], acol), al = frag(&lds.sp.A[buf][2][0][0], acol);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[a], 0, 0, 0);
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[a], 0, 0, 0);
-            }
-        } else if (BF16 == 1) {
+        if (BF16 == 1) {
 #pragma unroll
             for (int ks = 0; ks < KB / 16; ks++) {
                 bf16x8 a0, a1, b0;
@@ -332,6 +250,201 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         unsigned long long *o = g.trace + (size_t)blockIdx.x * 6;
         o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tr0; o[2] = tr1; o[3] = tr2; o[4] = wall_clock64(); o[5] = (unsigned long long)t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp32 results from the bf16 matrix cores: split ONCE, then a pure matrix kernel
+// ---------------------------------------------------------------------------------------------------
+// Every value that enters the product is split three ways, x = hi + mid + lo (bf16 each: all 24 mantissa bits), and the
+// K loop forms the six products down to 2^-16 (hh, hm, mh, mm, hl, lh; smallest first, fp32 accumulation): 6/16 of
+// the fp32-MFMA time.  Round 3's first form did the gather and the split inside the tile kernel, one 16-row block ahead
+// of the MFMAs: 2080 tiles each gathered and converted their own operands (every row panel 64 times over), the gather's
+// latency had one short K block to hide in, and the matrix pipe was 27 % busy (profiles/r3_pmc_sq.json).  Now
+//   * syrk_split_rows_kernel gathers the active rows once, forms w_k x_k and x_k (pair mode: of D[ids] - D[ids2]),
+//     splits them and writes bf16 planes in the order the tile kernel's LDS image has: per (operand, 16-row K block,
+//     128-column tile) one contiguous 12 KB image [plane][k / 8][column] of 16-byte entries (the eight consecutive k of
+//     a column: one MFMA fragment of one lane).  30 MB at K = 305, F = 8192; read back from L2 / Infinity Cache.
+//   * syrk_planes_kernel computes a 128 x 128 tile with four waves (64 x 64 each: 12 fragment reads feed 24 MFMAs per
+//     K block).  The images go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), three
+//     stages, two K blocks in flight while one is multiplied: counted vmcnt, one raw s_barrier per K block and nothing
+//     else in the loop but ds_read_b128 and MFMA.  Two workgroups per CU (72 KB of LDS each).
+// The arithmetic (w_k x_k rounded once in fp32, the split, the order of the six products and of the K blocks) is that
+// of the first form: results are bit-identical to it.
+constexpr int PL_KD = 16;                 // K rows per block
+constexpr int PL_IMG = 3 * 2 * TB * 16;   // bytes of one (operand, K block, column tile) image: 12,288
+constexpr int PL_STAGE = 2 * PL_IMG;      // A image + B image
+constexpr int PL_NSTAGE = 3;
+constexpr int PL_LDS = PL_NSTAGE * PL_STAGE;            // 73,728 B >= the epilogue's re-layout buffer (67,584 B)
+constexpr int NTP = 256;
+static_assert(PL_LDS >= TB * TLD * (int)sizeof(float), "the re-layout buffer must fit the stage memory");
+
+__global__ __launch_bounds__(256) void syrk_split_rows_kernel(const float *D, long ldd, const int32_t *ids, const int32_t *ids2,
+                                                              const float *w, const int *k_dev, int kmax, int nt, char *planes)
+{
+    const int ct = blockIdx.x, kb = blockIdx.y;
+    const int kact = min(*k_dev, kmax);
+    if (kb * PL_KD >= kact) return;
+    const int col = threadIdx.x & (TB - 1), lk = threadIdx.x >> 7;
+    const int nkb = kmax / PL_KD;
+    float v[8], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = kb * PL_KD + 8 * lk + j;
+        const float *row = D + (long)ids[k] * ldd + ct * TB + col;
+        v[j] = row[0];
+        if (ids2) v[j] -= D[(long)ids2[k] * ldd + ct * TB + col];      // Dist = Desc1 - Desc2, src/comp-uprjdists.cpp:327
+        wv[j] = w[k];
+    }
+    bf16x8 e[2][3];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int op = 0; op < 2; op++) {
+            const float x = op == 0 ? v[j] * wv[j] : v[j];              // w_k x_k for the A operand
+            const __bf16 h = (__bf16)x;
+            const float r1 = x - (float)h;
+            const __bf16 m = (__bf16)r1;
+            e[op][0][j] = h; e[op][1][j] = m; e[op][2][j] = (__bf16)(r1 - (float)m);
+        }
+#pragma unroll
+    for (int op = 0; op < 2; op++) {
+        bf16x8 *img = reinterpret_cast<bf16x8 *>(planes + (((long)op * nkb + kb) * nt + ct) * PL_IMG);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) img[(pl * 2 + lk) * TB + col] = e[op][pl];
+    }
+}
+
+template <bool SLAB, bool PACKED>
+__global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const char *planes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
+    const int nxcd = 8;
+    const int bid = blockIdx.x;
+    int t;
+    {
+        const int q = ntiles / nxcd, r = ntiles % nxcd, xcd = bid % nxcd, within = bid / nxcd;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int code = g.tile_map[t];
+    const int bi = code >> 16, bj = code & 0xffff;
+    const int i0 = bi * TB, j0 = bj * TB;
+    float *const ctile = PACKED ? g.C + (long)(bi * g.nt - bi * (bi - 1) / 2 + (bj - bi)) * (TB * TB) : g.C + (long)i0 * g.ldc + j0;
+    const long cld = PACKED ? TB : g.ldc;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                  // rows wm*64.., columns wn*64.. of the tile
+    const int lr = lane & 31, lk = lane >> 5;
+    const int kact = min(*g.k_dev, g.kmax);
+    const int nk = (kact + PL_KD - 1) / PL_KD;
+    const int nkb = g.kmax / PL_KD;
+
+    // this wave's six pieces (1 KB each) of a stage: waves 0, 1 bring the A image (w x of tile row bi), waves 2, 3 the B image
+    const long kstep = (long)g.nt * PL_IMG;
+    const char *src0 = planes + ((wave < 2 ? (long)bi : (long)nkb * g.nt + bj)) * PL_IMG + (wave & 1) * 6 * 1024 + lane * 16;
+    auto issue = [&](int kb, int stage) {
+        const char *src = src0 + kb * kstep;
+        char *dst = smem + stage * PL_STAGE + wave * 6 * 1024;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 1024),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    // old tile: requested inside the last K block, scalar row base + one lane offset
+    float oldv[2][2][16];
+    const bool use_old = (g.beta != 0.f);
+    const int old_lane = 4 * lk * (int)cld + lr;
+    auto fetch_old = [&]() {                                     // unconditional (the tile's memory exists); discarded below when beta = 0
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float *rowb = ctile + (long)(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * cld + wn * 64 + b * 32;
+                    oldv[a][b][r] = rowb[old_lane];
+                }
+    };
+
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk == 0) fetch_old();
+    int stage = 0;
+    for (int kb = 0; kb < nk; kb++) {
+        // my pieces of block kb have landed (the six of block kb + 1 may still be in flight); after the barrier everybody's have,
+        // and everybody has finished reading the stage that block kb + 2 is about to overwrite
+        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 2 < nk) issue(kb + 2, stage >= 1 ? stage - 1 : PL_NSTAGE - 1);
+        if (kb + 1 == nk) fetch_old();
+        const bf16x8 *Ai = reinterpret_cast<const bf16x8 *>(smem + stage * PL_STAGE);
+        const bf16x8 *Bi = reinterpret_cast<const bf16x8 *>(smem + stage * PL_STAGE + PL_IMG);
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                fa[x][pl] = Ai[(pl * 2 + lk) * TB + wm * 64 + 32 * x + lr];
+                fb[x][pl] = Bi[(pl * 2 + lk) * TB + wn * 64 + 32 * x + lr];
+            }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+            }
+        stage = stage + 1 < PL_NSTAGE ? stage + 1 : 0;
+    }
+    __syncthreads();                                          // the stage memory becomes the re-layout buffer
+
+    // ---- epilogue: dual average in registers, mirrored store straight from the accumulator layout, the tile itself
+    // through an LDS re-layout into whole 512-byte rows ---------------------------------------------------------
+    float (*T)[TLD] = reinterpret_cast<float (*)[TLD]>(smem);
+    const bool diag = (bi == bj);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int jl = wn * 64 + b * 32 + lr;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][b][4 * q + e] + (use_old ? g.beta * oldv[a][b][4 * q + e] : 0.f);
+                const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;           // rows il0 .. il0+3
+                if (!SLAB && !PACKED && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) T[il0 + e][jl] = o[e];
+            }
+        }
+    __syncthreads();
+    for (int f = tid; f < TB * (TB / 4); f += NTP) {
+        const int il = f / (TB / 4), cc = (f % (TB / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[il][cc]);
+        if (diag) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (cc + e < il) v[e] = T[cc + e][il];
+        }
+        *reinterpret_cast<f32x4 *>(&ctile[(long)il * cld + cc]) = v;
     }
 }
 
@@ -440,6 +553,32 @@ static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count
 }
 
 
+// Workspace of the split planes: one per device, grown on demand (2 operands x 6 bytes per staged value).
+static char *syrk_planes_buffer(size_t bytes)
+{
+    struct Entry { int dev; char *p; size_t cap; };
+    static std::vector<Entry> cache;
+    static std::mutex mu;
+    int dev = 0;
+    DLCO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry &e : cache)
+        if (e.dev == dev) {
+            if (e.cap < bytes) {
+                DLCO_HIP(hipDeviceSynchronize());              // launches that still read the old buffer
+                DLCO_HIP(hipFree(e.p));
+                e.p = nullptr; e.cap = 0;
+                DLCO_HIP(hipMalloc((void **)&e.p, bytes));
+                e.cap = bytes;
+            }
+            return e.p;
+        }
+    Entry e{dev, nullptr, bytes};
+    DLCO_HIP(hipMalloc((void **)&e.p, bytes));
+    cache.push_back(e);
+    return e.p;
+}
+
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16,
                   bool packed)
@@ -467,24 +606,36 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         g.tile_map = syrk_tile_map(g.nt, g.slab_t0, g.slab_nt, &n_map);
         DLCO_CHECK(n_map == ntiles, -2, "syrk: tile map size");
     }
-#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
-#define DLCO_SYRK_LAUNCH_PK(P, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, H, true>), dim3(ntiles), dim3(NT8), 0, s, g)
-    // precision of the products: 3 (default) = three-way split bf16, fp32-level results at 3/8 of the fp32 matrix time
-    // (0.189 against 0.219 ms per launch at K = 305: the launch is then spread over matrix time, conversions, LDS and its
-    // HBM phase instead of waiting on the fp32 MFMA pipe); 0 = fp32 MFMA, a k-ordered fmaf chain (DLCO_SYRK_FP32=1);
-    // 1 = operands rounded to bf16 once (cfg.grad_bf16, the configs[4] variant)
+    // precision of the products: 3 (default) = three-way split bf16 on pre-split planes, fp32-level results at 3/8 of
+    // the fp32 matrix time; 0 = fp32 MFMA, a k-ordered fmaf chain (DLCO_SYRK_FP32=1); 1 = operands rounded to bf16
+    // once (cfg.grad_bf16, the configs[4] variant)
     static const bool exact_fp32 = std::getenv("DLCO_SYRK_FP32") != nullptr;
     const int prec = bf16 ? 1 : (exact_fp32 ? 0 : 3);
+    if (prec == 3) {
+        // split once, then the matrix kernel (see syrk_planes_kernel)
+        char *planes = syrk_planes_buffer((size_t)2 * (kmax / PL_KD) * g.nt * PL_IMG);
+        hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
+        static bool attr = false;
+        if (!attr) {
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
+            attr = true;
+        }
+        if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
+        else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
+        else hipLaunchKernelGGL((syrk_planes_kernel<false, false>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
+        DLCO_HIP(hipGetLastError());
+        return true;
+    }
+#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
+#define DLCO_SYRK_LAUNCH_PK(P, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, H, true>), dim3(ntiles), dim3(NT8), 0, s, g)
     if (packed) {
         if (prec == 1) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 1); else DLCO_SYRK_LAUNCH_PK(false, 1); }
-        else if (prec == 3) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 3); else DLCO_SYRK_LAUNCH_PK(false, 3); }
         else { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 0); else DLCO_SYRK_LAUNCH_PK(false, 0); }
     } else if (prec == 1) {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 1); else DLCO_SYRK_LAUNCH(false, true, 1); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 1); else DLCO_SYRK_LAUNCH(false, false, 1); }
-    } else if (prec == 3) {
-        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 3); else DLCO_SYRK_LAUNCH(false, true, 3); }
-        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 3); else DLCO_SYRK_LAUNCH(false, false, 3); }
     } else {
         if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 0); else DLCO_SYRK_LAUNCH(false, true, 0); }
         else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 0); else DLCO_SYRK_LAUNCH(false, false, 0); }

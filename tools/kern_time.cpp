@@ -111,7 +111,7 @@ int main(int argc, char **argv)
         std::printf("chol_inverse128 n=%3d  %.1f us  |Linv M Linv^T - I|max = %.2e\n", n, ms * 1e3, err);
         }
 
-        // ---- Jacobi on a nearly diagonal symmetric matrix (steady-state Rayleigh-Ritz) ------------
+        // ---- Jacobi on a nearly diagonal symmetric matrix (steady-state Rayleigh-Ritz); eigenvectors = ROWS of V ----
         std::vector<float> T((size_t)n * ld, 0.f);
         for (int i = 0; i < n; i++)
             for (int j = 0; j <= i; j++) {
@@ -131,17 +131,49 @@ int main(int argc, char **argv)
         for (int j = 0; j < n; j++) {
             for (int i = 0; i < n; i++) {
                 double acc = 0;
-                for (int k = 0; k < n; k++) acc += (double)T[(size_t)i * ld + k] * V[(size_t)k * ld + j];
-                res = std::max(res, std::fabs(acc - (double)e[j] * V[(size_t)i * ld + j]));
+                for (int k = 0; k < n; k++) acc += (double)T[(size_t)i * ld + k] * V[(size_t)j * ld + k];
+                res = std::max(res, std::fabs(acc - (double)e[j] * V[(size_t)j * ld + i]));
             }
             for (int k = 0; k < n; k++) {
                 double acc = 0;
-                for (int i = 0; i < n; i++) acc += (double)V[(size_t)i * ld + j] * V[(size_t)i * ld + k];
+                for (int i = 0; i < n; i++) acc += (double)V[(size_t)j * ld + i] * V[(size_t)k * ld + i];
                 orth = std::max(orth, std::fabs(acc - (j == k ? 1.0 : 0.0)));
             }
         }
         std::printf("jacobi_eigh     n=%3d  %.1f us  sweeps %d (%.1f us/sweep)  |TV - VE|max = %.2e  |V^T V - I|max = %.2e\n", n,
                     msj * 1e3, sweeps, msj * 1e3 / std::max(1, sweeps), res, orth);
+        // ---- the same on a matrix that needs large rotations: M above (eigenvalues clustered around 1) and a wide spectrum ----
+        for (int kind = 0; kind < 2; kind++) {
+            std::vector<float> H((size_t)n * ld, 0.f);
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) {
+                    if (kind == 0) { H[(size_t)i * ld + j] = M[(size_t)i * ld + j]; continue; }
+                    double acc = 0;                               // B diag(10^(-6 k / K)) B^T / K: six decades
+                    for (int k = 0; k < K; k++) acc += B[(size_t)i * K + k] * B[(size_t)j * K + k] * std::pow(10.0, -6.0 * k / K) * (k % 7 == 0 ? 100.0 : 1.0);
+                    H[(size_t)i * ld + j] = (float)(acc / K);
+                }
+            hipMemcpy(dT.p, H.data(), H.size() * 4, hipMemcpyHostToDevice);
+            const float msh = time_ms(s, n > 160 ? 3 : 20, [&] { jacobi_eigh(dT.p, ld, n, ev.p, dV.p, ld, work.p, sw.p, s); });
+            hipMemcpy(&sweeps, sw.p, 4, hipMemcpyDeviceToHost);
+            hipMemcpy(V.data(), dV.p, T.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(e.data(), ev.p, n * 4, hipMemcpyDeviceToHost);
+            double resh = 0, orthh = 0, emax = 0;
+            for (int j = 0; j < n; j++) {
+                emax = std::max(emax, (double)std::fabs(e[j]));
+                for (int i = 0; i < n; i++) {
+                    double acc = 0;
+                    for (int k = 0; k < n; k++) acc += (double)H[(size_t)i * ld + k] * V[(size_t)j * ld + k];
+                    resh = std::max(resh, std::fabs(acc - (double)e[j] * V[(size_t)j * ld + i]));
+                }
+                for (int k = 0; k < n; k++) {
+                    double acc = 0;
+                    for (int i = 0; i < n; i++) acc += (double)V[(size_t)j * ld + i] * V[(size_t)k * ld + i];
+                    orthh = std::max(orthh, std::fabs(acc - (j == k ? 1.0 : 0.0)));
+                }
+            }
+            std::printf("jacobi_eigh     n=%3d  dense %s  %.1f us  sweeps %d  |HV - VE|max / |E|max = %.2e  |V^T V - I|max = %.2e\n", n,
+                        kind == 0 ? "clustered" : "wide     ", msh * 1e3, sweeps, resh / emax, orthh);
+        }
     }
     if (small_only) return 0;
     // ---- slab-mode kernels at the 8-GPU shape (F = 8192, slab of 1024 columns, global batch 1600+1600) ----
