@@ -7,19 +7,17 @@
 // order P^T diag(rho) P - N^T diag(kappa) N; rows with zero weight are not in the list).
 //
 // Design (MI355X): the output is symmetric, so only the 128x128 tiles on or above the
-// diagonal are computed (nt(nt+1)/2 workgroups, dealt to the 8 XCDs in contiguous chunks so
-// that neighbouring tiles share their row panels in one L2) and each tile is also stored
-// transposed.  Both MFMA operands are k-major images of gathered rows (lane l reads element
-// l&31 of row 2kk + (l>>5): conflict-free ds_read_b32), staged through registers with the
-// row ids one tile ahead of the data so that the gather's two dependent loads never sit in
-// the same iteration.  The hot loop is branch-free; the row list is zero-padded to the tile
-// depth by the kernel that builds it.  Epilogue: dual-average update in registers, direct
-// store of the tile, transposed store through LDS as whole 512-byte rows.  fp32 results: by default from
-// the bf16 matrix cores with both operands split three ways at staging time (see PRE in the kernel), or
-// from v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain) with DLCO_SYRK_FP32=1.
+// diagonal are computed (nt(nt+1)/2 workgroups, dealt to the 8 XCDs in contiguous chunks of 8 x 8
+// super-blocks so that neighbouring tiles share their row panels in one L2).  fp32 results come by
+// default from the bf16 matrix cores: the active rows are split three ways ONCE (syrk_split_rows_kernel)
+// and a pure matrix kernel fed by LDS-DMA multiplies the planes (syrk_planes_kernel, below).  The older
+// kernel that gathers inside the tile loop (syrk_rda_kernel8) remains for the two other arithmetics:
+// v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain (DLCO_SYRK_FP32=1), and operands rounded to bf16 once
+// (cfg.grad_bf16, BASELINE configs[4]).  Epilogue everywhere: dual-average update in registers.
 #include "dlco_internal.hpp"
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace dlco {
@@ -274,10 +272,7 @@ __global__ __launch_bounds__(NT8, 4) void syrk_rda_kernel8(SyrkDev g)
 constexpr int PL_KD = 16;                 // K rows per block
 constexpr int PL_IMG = 3 * 2 * TB * 16;   // bytes of one (operand, K block, column tile) image: 12,288
 constexpr int PL_STAGE = 2 * PL_IMG;      // A image + B image
-constexpr int PL_NSTAGE = 3;
-constexpr int PL_LDS = PL_NSTAGE * PL_STAGE;            // 73,728 B >= the epilogue's re-layout buffer (67,584 B)
 constexpr int NTP = 256;
-static_assert(PL_LDS >= TB * TLD * (int)sizeof(float), "the re-layout buffer must fit the stage memory");
 
 __global__ __launch_bounds__(256) void syrk_split_rows_kernel(const float *D, long ldd, const int32_t *ids, const int32_t *ids2,
                                                               const float *w, const int *k_dev, int kmax, int nt, char *planes)
@@ -315,10 +310,12 @@ __global__ __launch_bounds__(256) void syrk_split_rows_kernel(const float *D, lo
     }
 }
 
-template <bool SLAB, bool PACKED>
-__global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const char *planes)
+template <bool SLAB, bool PACKED, int NST>
+__global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(SyrkDev g, const char *planes)
 {
+    constexpr int PL_NSTAGE = NST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long tr0 = g.trace ? wall_clock64() : 0ull;
     const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
     const int nxcd = 8;
     const int bid = blockIdx.x;
@@ -361,35 +358,36 @@ __global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const ch
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    // old tile: requested inside the last K block, scalar row base + one lane offset
+    // old tile: 64 values per lane (scalar row base + one lane offset), requested inside the last K block (no DMA follows it)
     float oldv[2][2][16];
     const bool use_old = (g.beta != 0.f);
     const int old_lane = 4 * lk * (int)cld + lr;
-    auto fetch_old = [&]() {                                     // unconditional (the tile's memory exists); discarded below when beta = 0
+    auto fetch_quadrant = [&](int a, int b, float (&dst)[16]) {  // unconditional (the tile's memory exists); discarded below when beta = 0
 #pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float *rowb = ctile + (long)(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * cld + wn * 64 + b * 32;
-                    oldv[a][b][r] = rowb[old_lane];
-                }
+        for (int r = 0; r < 16; r++) {
+            const float *rowb = ctile + (long)(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * cld + wn * 64 + b * 32;
+            dst[r] = rowb[old_lane];
+        }
     };
-
+    constexpr int DEPTH = NST - 1;                            // K blocks requested ahead of the one being multiplied
     if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk == 0) fetch_old();
+    if (DEPTH > 1 && nk > 1) issue(1, 1);
+    const unsigned long long tr1 = g.trace ? wall_clock64() : 0ull;
     int stage = 0;
-    for (int kb = 0; kb < nk; kb++) {
-        // my pieces of block kb have landed (the six of block kb + 1 may still be in flight); after the barrier everybody's have,
-        // and everybody has finished reading the stage that block kb + 2 is about to overwrite
-        if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // One K block.  LAST: the old tile is requested here; VM: how many younger memory operations than block kb's pieces
+    // this wave has in flight at the top; ISSUE: block kb + DEPTH exists.
+    auto iteration = [&](int kb, auto last_c, auto vm_c, auto issue_c) {
+        constexpr int VM = decltype(vm_c)::value;
+        constexpr bool LAST = decltype(last_c)::value, ISSUE = decltype(issue_c)::value;
+        // my pieces of block kb have landed; after the barrier everybody's have, and everybody has finished reading the
+        // stage that block kb + DEPTH is about to overwrite
+        if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kb + 2 < nk) issue(kb + 2, stage >= 1 ? stage - 1 : PL_NSTAGE - 1);
-        if (kb + 1 == nk) fetch_old();
+        if constexpr (LAST) {
+            fetch_quadrant(0, 0, oldv[0][0]); fetch_quadrant(0, 1, oldv[0][1]); fetch_quadrant(1, 0, oldv[1][0]); fetch_quadrant(1, 1, oldv[1][1]);
+        }
         const bf16x8 *Ai = reinterpret_cast<const bf16x8 *>(smem + stage * PL_STAGE);
         const bf16x8 *Bi = reinterpret_cast<const bf16x8 *>(smem + stage * PL_STAGE + PL_IMG);
         bf16x8 fa[2][3], fb[2][3];
@@ -400,6 +398,7 @@ __global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const ch
                 fa[x][pl] = Ai[(pl * 2 + lk) * TB + wm * 64 + 32 * x + lr];
                 fb[x][pl] = Bi[(pl * 2 + lk) * TB + wn * 64 + 32 * x + lr];
             }
+        if constexpr (ISSUE) issue(kb + DEPTH, stage >= 1 ? stage - 1 : PL_NSTAGE - 1);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -411,13 +410,38 @@ __global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const ch
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
             }
+        // issue order inside the iteration: fragment reads first, then the six DMA pieces spread between the MFMAs (a piece
+        // costs the wave ~60 cycles of issue; between two MFMAs that is time the matrix pipe spends on the MFMA before)
+        if constexpr (ISSUE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+        }
         stage = stage + 1 < PL_NSTAGE ? stage + 1 : 0;
+    };
+    using std::integral_constant;
+    typedef integral_constant<bool, true> Yes;
+    typedef integral_constant<bool, false> No;
+    typedef integral_constant<int, 6 * (DEPTH - 1)> Ahead;   // the pieces of the blocks between kb and kb + DEPTH
+    typedef integral_constant<int, 0> None;
+    if (nk > 0) {
+        for (int kb = 0; kb + DEPTH < nk; kb++) iteration(kb, No{}, Ahead{}, Yes{});
+        if (DEPTH > 1 && nk > 1) iteration(nk - 2, No{}, Ahead{}, No{});
+        iteration(nk - 1, Yes{}, None{}, No{});
+    } else {
+        fetch_quadrant(0, 0, oldv[0][0]); fetch_quadrant(0, 1, oldv[0][1]); fetch_quadrant(1, 0, oldv[1][0]); fetch_quadrant(1, 1, oldv[1][1]);
     }
-    __syncthreads();                                          // the stage memory becomes the re-layout buffer
+    const unsigned long long tr2 = g.trace ? wall_clock64() : 0ull;
 
-    // ---- epilogue: dual average in registers, mirrored store straight from the accumulator layout, the tile itself
-    // through an LDS re-layout into whole 512-byte rows ---------------------------------------------------------
-    float (*T)[TLD] = reinterpret_cast<float (*)[TLD]>(smem);
+    // ---- epilogue: dual average in registers, every store straight from the accumulator layout (a lane holds a column:
+    // 32 lanes write 128 contiguous bytes of a row; the mirrored copy of the unpacked layout takes four rows of a column
+    // as 16 bytes).  A diagonal tile is made exactly symmetric: what lies above the diagonal is stored twice, what lies
+    // below it is not stored at all. ---------------------------------------------------------------------------------
     const bool diag = (bi == bj);
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -430,21 +454,26 @@ __global__ __launch_bounds__(NTP, 2) void syrk_planes_kernel(SyrkDev g, const ch
 #pragma unroll
                 for (int e = 0; e < 4; e++) o[e] = g.alpha * acc[a][b][4 * q + e] + (use_old ? g.beta * oldv[a][b][4 * q + e] : 0.f);
                 const int il0 = wm * 64 + a * 32 + 8 * q + 4 * lk;           // rows il0 .. il0+3
-                if (!SLAB && !PACKED && !diag) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+                if (diag) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) T[il0 + e][jl] = o[e];
+                    for (int e = 0; e < 4; e++) {
+                        const int il = il0 + e;
+                        if (il <= jl) ctile[(long)il * cld + jl] = o[e];
+                        if (il < jl) ctile[(long)jl * cld + il] = o[e];
+                    }
+                } else {
+                    if (!SLAB && !PACKED) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ctile[(long)(il0 + e) * cld + jl] = o[e];
+                }
             }
         }
-    __syncthreads();
-    for (int f = tid; f < TB * (TB / 4); f += NTP) {
-        const int il = f / (TB / 4), cc = (f % (TB / 4)) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[il][cc]);
-        if (diag) {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (cc + e < il) v[e] = T[cc + e][il];
-        }
-        *reinterpret_cast<f32x4 *>(&ctile[(long)il * cld + cc]) = v;
+    if (g.trace && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = g.trace + (size_t)blockIdx.x * 6;
+        o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tr0; o[2] = tr1; o[3] = tr2; o[4] = wall_clock64(); o[5] = (unsigned long long)t;
     }
 }
 
@@ -615,17 +644,23 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         // split once, then the matrix kernel (see syrk_planes_kernel)
         char *planes = syrk_planes_buffer((size_t)2 * (kmax / PL_KD) * g.nt * PL_IMG);
         hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
+        // three stages of 24 KB, two workgroups per CU.  (Two stages and three workgroups per CU - twelve waves - measured
+        // the same: 0.133 against 0.132 ms per launch.  What the launch loses is spread over the K loop, where two
+        // workgroups sharing a CU reach 72 % of the matrix rate, the 5 us of a tile's 23 outside the loop - first
+        // pieces, old tile, stores - and the last of its 4.06 rounds.)
+        constexpr int NST = 3;
         static bool attr = false;
         if (!attr) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PL_LDS));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
             attr = true;
         }
-        if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
-        else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
-        else hipLaunchKernelGGL((syrk_planes_kernel<false, false>), dim3(ntiles), dim3(NTP), PL_LDS, s, g, planes);
+        if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+        else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+        else hipLaunchKernelGGL((syrk_planes_kernel<false, false, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
         DLCO_HIP(hipGetLastError());
+        if (tracing) syrk_dump_trace(trace_path, trace_buf, ntiles, s);
         return true;
     }
 #define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
