@@ -512,180 +512,200 @@ void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, 
                        sweeps_out, stop_cos, lam_cut);
 }
 
-// ---- 160 < n <= 2048: the same blocks, one workgroup (one wave) per block pair, MANY CUs ------------------------------
+// ---- 160 < n <= 2048: the same blocks, one workgroup per block pair, MANY CUs ----------------------------------------
 // Blocks of several hundred rows only occur in the start-up transient of a run (from W = 0 the rank overshoots to 300 -
-// 900 before it settles), but there the one-workgroup kernel in global memory cost 6 ms a call, two thirds of the
-// transient's 3.7 s.  The block tournament needs no shared LDS image: the matrix G = sym(T) + sigma I stays in global
-// memory (L2 / Infinity Cache resident), a workgroup of ONE wave takes the two blocks of its pair into its own LDS, rotates
-// the 64 cross pairs there (eight wave-private inner rounds, both columns of a pair read from and written to LDS) and writes
-// the sixteen columns back; between two rounds of the tournament all workgroups meet at a grid barrier.  n / 16 workgroups on
-// as many CUs, n / 8 - 1 barriers per sweep.
-//   * Hand-off through global memory between CUs on different XCDs: every storing wave drains its stores, lane 0 issues an
-//     agent-scope release, then arrives at a monotonic counter; after the poll an agent-scope acquire, then plain loads.
-//   * The grid is at most 128 one-wave workgroups: always co-resident.  Every spin is bounded; a barrier that does not
-//     complete sets *sweeps_out = -1 and every workgroup leaves.
+// 900 before it settles), but there they are most of the time: 45 % of the first hundred steps went into this solver
+// when a workgroup was ONE wave that fetched its sixteen columns one after the other (a dependent L2 round trip each)
+// and rotated 400-row columns with eight lanes.  The block tournament needs no shared LDS image: the matrix G = T +
+// sigma I stays in global memory (L2 / Infinity Cache resident), the workgroup of a block pair brings the two blocks
+// into its own LDS - by LDS-DMA, every piece of all sixteen columns in flight at once - rotates the 64 cross pairs
+// there (eight inner rounds of eight pairs; the rows of a pair are dealt to the four waves, 32 lanes per pair, the
+// partial cross products meet in LDS) and writes the sixteen columns back; between two rounds of the tournament all
+// workgroups meet at a grid barrier.  n / 16 workgroups on as many CUs, n / 8 - 1 barriers per sweep.
+//   * Hand-off through global memory between CUs on different XCDs: every storing wave drains its stores and issues an
+//     agent-scope release, the workgroup meets, thread 0 arrives at a monotonic counter and polls it; after the poll
+//     every wave issues an agent-scope acquire, then plain loads.
+//   * The grid is at most 128 workgroups of 256 threads: always co-resident.  Every spin is bounded; a barrier that
+//     does not complete sets *sweeps_out = -1 and every workgroup leaves.
+// T is taken as symmetric up to rounding (row j becomes column j), as in the one-workgroup kernel above.
 struct JmwDev {
     const float *T; long ldt; int n;
     float *evals, *Vout; long ldv;
     float *G;                     // [ncol][ldc] work image of the columns, ldc = n rounded up to 32
-    float *lam;                   // [ncol] + [ncol] (inverse norms) + [ncol] ranks
+    float *lam;                   // [ncol] + [ncol] (inverse norms)
     unsigned *sync;               // [0] barrier counter, [1] timeout flag, [2 + sweep] max cosine of a sweep, [50] Gershgorin bound (float bits); zeroed by the host
     int *sweeps_out;
     float stop_cos, lam_cut;
     int ldc, nbe;
 };
 
-__device__ __forceinline__ bool jmw_grid_sync(unsigned *sync, unsigned nwg, unsigned &target)
+constexpr int JMW_T = 256;
+
+// all threads of the workgroup call it; false: the barrier timed out somewhere
+__device__ __forceinline__ bool jmw_grid_sync(unsigned *sync, unsigned nwg, unsigned &target, int *flag_lds)
 {
-    // one wave per workgroup: lane 0 speaks for it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
-    bool ok = true;
-    if ((threadIdx.x & 63) == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        target += nwg;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this wave's stores are visible to the other CUs ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // ... and so are the other waves' of this workgroup
+    target += nwg;
+    if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        int ok = 1;
         while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 22) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
+                ok = 0;
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *flag_lds = ok;
     }
-    return __shfl(ok ? 1 : 0, 0, 64) != 0;
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *flag_lds != 0;
 }
 
-__global__ __launch_bounds__(64) void jacobi_mw_kernel(JmwDev g)
+__global__ __launch_bounds__(JMW_T) void jacobi_mw_kernel(JmwDev g)
 {
     extern __shared__ __attribute__((aligned(16))) float sh[];
-    const int n = g.n, ldc = g.ldc, nch = ldc >> 5;            // 32-float (4 floats x 8 lanes) pieces per column
-    const int lane = threadIdx.x, grp = lane >> 3, l = lane & 7;
+    const int n = g.n, ldc = g.ldc, nq = ldc >> 2;             // 16-byte chunks per column
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane >> 3, l = lane & 7;
+    const int q0 = l + 8 * wave;                               // this thread's chunks of a pair's columns: q0, q0 + 32, ...
     const int k = blockIdx.x, nwg = gridDim.x, nbe = g.nbe, m = nbe - 1, ncol = 8 * nbe;
-    float *colA = sh, *colB = sh + 8 * (size_t)ldc;             // the pair's two blocks, column c of a block at c * ldc
-    float *nA = sh + 16 * (size_t)ldc, *nB = nA + 8;            // tracked squared norms of the sixteen columns
+    float *cols = sh;                                           // sixteen columns: block A 0-7, block B 8-15, column c at c * ldc
+    float *nrm = sh + 16 * (size_t)ldc;                         // [16] tracked squared norms
+    float *red = nrm + 16;                                      // [2][8][4] partial cross products of a step
+    float *wred = red + 64;                                     // [4] per-wave maxima
+    int *flag = reinterpret_cast<int *>(wred + 4);
     unsigned target = 0;
 
-    // ---- sigma = 1.01 * max_i sum_j |T_ij| + tiny (Gershgorin): rows dealt to the workgroups, maximum through a word --------
+    // ---- sigma = 1.01 * max_i sum_j |T_ij| + tiny (Gershgorin): rows dealt to the waves of all workgroups ------------------
     {
         float rmax = 0.f;
-        for (int i = k; i < n; i += nwg) {
+        for (int i = 4 * k + wave; i < n; i += 4 * nwg) {
             float sacc = 0.f;
             for (int j = lane; j < n; j += 64) sacc += fabsf(g.T[(long)i * g.ldt + j]);
             rmax = fmaxf(rmax, wsum(sacc));
         }
         if (lane == 0) atomicMax(g.sync + 50, __float_as_uint(rmax));   // non-negative floats order like their bits
     }
-    if (!jmw_grid_sync(g.sync, nwg, target)) { if (k == 0 && lane == 0) *g.sweeps_out = -1; return; }
+    if (!jmw_grid_sync(g.sync, nwg, target, flag)) { if (k == 0 && tid == 0) *g.sweeps_out = -1; return; }
     const float sigma = 1.01f * __uint_as_float(__hip_atomic_load(g.sync + 50, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1e-30f;
     const float cut2 = g.lam_cut + sigma > 0.f ? (g.lam_cut + sigma) * (g.lam_cut + sigma) : 0.f;
-    // ---- G = sym(T) + sigma I, zero padded: this workgroup writes the sixteen columns of blocks 2k, 2k+1 ------------------
-    for (int c = 0; c < 16; c++) {
+    // ---- G = T + sigma I, zero padded: this workgroup writes the sixteen columns of blocks 2k, 2k+1 -----------------------
+    for (int c = wave; c < 16; c += 4) {
         const int j = 16 * k + c;
         for (int i = lane; i < ldc; i += 64) {
             float v = 0.f;
-            if (i < n && j < n) v = 0.5f * (g.T[(long)i * g.ldt + j] + g.T[(long)j * g.ldt + i]) + (i == j ? sigma : 0.f);
+            if (i < n && j < n) v = g.T[(long)j * g.ldt + i] + (i == j ? sigma : 0.f);
             g.G[(size_t)j * ldc + i] = v;
         }
     }
-    if (!jmw_grid_sync(g.sync, nwg, target)) { if (k == 0 && lane == 0) *g.sweeps_out = -1; return; }
+    if (!jmw_grid_sync(g.sync, nwg, target, flag)) { if (k == 0 && tid == 0) *g.sweeps_out = -1; return; }
 
     const float tol = 3e-6f;
-    // block (8 columns) global <-> LDS, with the exact squared norm of every column on the way in
-    auto load_block = [&](int b, float *dst, float *nrm) {
-        for (int c = 0; c < 8; c++) {
-            const float *src = g.G + (size_t)(8 * b + c) * ldc;
-            float sq = 0.f;
-            for (int i = lane * 4; i < ldc; i += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i);
-                *reinterpret_cast<f32x4 *>(dst + (size_t)c * ldc + i) = v;
-                sq += dot4(v, v);
+    // two blocks (sixteen columns) global -> LDS, every piece in flight at once; then the exact squared norms
+    auto load_blocks = [&](int ba, int bb) {
+        for (int c = wave; c < 16; c += 4) {
+            const float *src = g.G + (size_t)(8 * (c < 8 ? ba : bb) + (c & 7)) * ldc;
+            float *dst = cols + (size_t)c * ldc;
+            for (int p0 = 0; p0 < ldc; p0 += 256) {
+                if (p0 + 4 * lane < ldc)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p0 + 4 * lane),
+                                                     (__attribute__((address_space(3))) void *)(dst + p0), 16, 0, 0);
             }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = wave; c < 16; c += 4) {
+            const f32x4 *col = reinterpret_cast<const f32x4 *>(cols + (size_t)c * ldc);
+            float sq = 0.f;
+            for (int q = lane; q < nq; q += 64) { const f32x4 v = col[q]; sq += dot4(v, v); }
             sq = wsum(sq);
             if (lane == 0) nrm[c] = sq;
         }
+        __syncthreads();
     };
-    auto store_block = [&](int b, const float *src) {
-        for (int c = 0; c < 8; c++) {
-            float *dst = g.G + (size_t)(8 * b + c) * ldc;
-            for (int i = lane * 4; i < ldc; i += 256) *reinterpret_cast<f32x4 *>(dst + i) = *reinterpret_cast<const f32x4 *>(src + (size_t)c * ldc + i);
+    auto store_blocks = [&](int ba, int bb) {
+        for (int c = wave; c < 16; c += 4) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(g.G + (size_t)(8 * (c < 8 ? ba : bb) + (c & 7)) * ldc);
+            const f32x4 *col = reinterpret_cast<const f32x4 *>(cols + (size_t)c * ldc);
+            for (int q = lane; q < nq; q += 64) dst[q] = col[q];
         }
     };
     float off_max = 0.f;
-    // one rotation of the pair (px: squared norm *na, py: *nb), both columns in LDS; lane group of 8 lanes, lane l owns pieces l + 8 e
-    auto rotate_pair = [&](float *px, float *py, float *na, float *nb) {
+    int parity = 0;
+    // one rotation step: the pair (columns cx, cy of the sixteen) of this thread's lane group; 32 lanes (8 per wave) per pair
+    auto rotate_step = [&](int cx, int cy) {
+        f32x4 *px = reinterpret_cast<f32x4 *>(cols + (size_t)cx * ldc), *py = reinterpret_cast<f32x4 *>(cols + (size_t)cy * ldc);
         float c = 0.f;
-        for (int e = 0; e < nch; e++) {
-            const int o = 4 * (l + 8 * e);
-            c += dot4(*reinterpret_cast<const f32x4 *>(px + o), *reinterpret_cast<const f32x4 *>(py + o));
-        }
+        for (int q = q0; q < nq; q += 32) c += dot4(px[q], py[q]);
         c = row8_sum(c);
-        const float a = *na, b = *nb;
+        float *rp = red + (parity * 8 + grp) * 4;
+        if (l == 0) rp[wave] = c;
+        __syncthreads();
+        c = (rp[0] + rp[1]) + (rp[2] + rp[3]);
+        const float a = nrm[cx], b = nrm[cy];
         const float ab = a * b;
         const float off = ab > 0.f ? fabsf(c) * __builtin_amdgcn_rsqf(ab) : 0.f;
         off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
+        float t = 0.f;
         if (off > tol) {
-            float t, cs, sn;
+            float cs, sn;
             rotation(a, b, c, t, cs, sn);
-            for (int e = 0; e < nch; e++) {
-                const int o = 4 * (l + 8 * e);
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(px + o), y = *reinterpret_cast<const f32x4 *>(py + o);
-                *reinterpret_cast<f32x4 *>(px + o) = cs * x - sn * y;
-                *reinterpret_cast<f32x4 *>(py + o) = sn * x + cs * y;
+            for (int q = q0; q < nq; q += 32) {
+                const f32x4 x = px[q], y = py[q];
+                px[q] = cs * x - sn * y;
+                py[q] = sn * x + cs * y;
             }
-            if (l == 0) { *na = a - t * c; *nb = b + t * c; }
         }
+        __syncthreads();                                        // everybody has read the norms of this step
+        if (wave == 0 && l == 0 && off > tol) { nrm[cx] = a - t * c; nrm[cy] = b + t * c; }
+        parity ^= 1;
     };
 
     int sweep = 0;
     bool alive = true;
     for (; sweep < 40 && alive; sweep++) {
         off_max = 0.f;
-        // ---- pairs inside blocks 2k (lane groups 0-3) and 2k+1 (groups 4-7): seven wave-private rounds -------------------
-        load_block(2 * k, colA, nA);
-        load_block(2 * k + 1, colB, nB);
+        // ---- pairs inside blocks 2k (lane groups 0-3) and 2k+1 (groups 4-7): seven rounds ---------------------------------
+        load_blocks(2 * k, 2 * k + 1);
         {
-            float *base = grp < 4 ? colA : colB, *nb_ = grp < 4 ? nA : nB;
-            const int kk = grp & 3;
+            const int base = grp < 4 ? 0 : 8, kk = grp & 3;
             for (int r = 0; r < 7; r++) {
                 const int pa = kk == 0 ? 7 : (r + kk) % 7, pb = kk == 0 ? r : (r - kk + 7) % 7;
-                rotate_pair(base + (size_t)pa * ldc, base + (size_t)pb * ldc, nb_ + pa, nb_ + pb);
+                rotate_step(base + pa, base + pb);
             }
         }
-        store_block(2 * k, colA);
-        store_block(2 * k + 1, colB);
-        if (!jmw_grid_sync(g.sync, nwg, target)) { alive = false; break; }
+        __syncthreads();
+        store_blocks(2 * k, 2 * k + 1);
+        if (!jmw_grid_sync(g.sync, nwg, target, flag)) { alive = false; break; }
         // ---- the blocks meet: round r pairs block m with block r, and (r + k) mod m with (r - k) mod m -------------------
         for (int r = 0; r < m; r++) {
             const int ba = k == 0 ? m : (r + k) % m, bb = k == 0 ? r : (r - k + m) % m;
-            load_block(ba, colA, nA);
-            load_block(bb, colB, nB);
-            for (int kk = 0; kk < 8; kk++) {
-                const int cb = (grp + kk) & 7;
-                rotate_pair(colA + (size_t)grp * ldc, colB + (size_t)cb * ldc, nA + grp, nB + cb);
-            }
-            store_block(ba, colA);
-            store_block(bb, colB);
-            if (!jmw_grid_sync(g.sync, nwg, target)) { alive = false; break; }
+            load_blocks(ba, bb);
+            for (int kk = 0; kk < 8; kk++) rotate_step(grp, 8 + ((grp + kk) & 7));
+            __syncthreads();
+            store_blocks(ba, bb);
+            if (!jmw_grid_sync(g.sync, nwg, target, flag)) { alive = false; break; }
         }
         if (!alive) break;
         // ---- the sweep's largest cosine, over all workgroups --------------------------------------------------------------
         off_max = wmax(off_max);
         if (lane == 0) atomicMax(g.sync + 2 + sweep, __float_as_uint(off_max));      // non-negative floats order like their bits
-        if (!jmw_grid_sync(g.sync, nwg, target)) { alive = false; break; }
+        if (!jmw_grid_sync(g.sync, nwg, target, flag)) { alive = false; break; }
         const float mx = __uint_as_float(__hip_atomic_load(g.sync + 2 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (mx <= g.stop_cos) { sweep++; break; }
     }
-    if (!alive) { if (k == 0 && lane == 0) *g.sweeps_out = -1; return; }
-    if (k == 0 && lane == 0 && g.sweeps_out) *g.sweeps_out = sweep;
+    if (!alive) { if (k == 0 && tid == 0) *g.sweeps_out = -1; return; }
+    if (k == 0 && tid == 0 && g.sweeps_out) *g.sweeps_out = sweep;
 
-    // ---- eigenvalues lambda = |g| - sigma, eigenvectors g / |g|, sorted descending ------------------------------------------
+    // ---- eigenvalues lambda = |g| - sigma, eigenvectors g / |g| (the rows of V), sorted descending ---------------------------
     float *lam = g.lam, *inv = g.lam + ncol;
-    for (int c = 0; c < 16; c++) {
+    for (int c = wave; c < 16; c += 4) {
         const int j = 16 * k + c;
         if (j >= n) break;
         float d = 0.f;
@@ -693,8 +713,8 @@ __global__ __launch_bounds__(64) void jacobi_mw_kernel(JmwDev g)
         d = wsum(d);
         if (lane == 0) { const float nr = sqrtf(d); lam[j] = nr - sigma; inv[j] = nr > 0.f ? 1.f / nr : 0.f; }
     }
-    if (!jmw_grid_sync(g.sync, nwg, target)) { if (k == 0 && lane == 0) *g.sweeps_out = -1; return; }
-    for (int c = 0; c < 16; c++) {
+    if (!jmw_grid_sync(g.sync, nwg, target, flag)) { if (k == 0 && tid == 0) *g.sweeps_out = -1; return; }
+    for (int c = wave; c < 16; c += 4) {
         const int j = 16 * k + c;
         if (j >= n) break;
         const float me = lam[j];
@@ -743,13 +763,13 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         if (!sync_words) DLCO_HIP(hipMalloc((void **)&sync_words, 64 * sizeof(unsigned)));
         DLCO_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
         g.sync = sync_words; g.sweeps_out = sweeps_out; g.stop_cos = stop_cos; g.lam_cut = lam_cut;
-        const size_t lds = ((size_t)16 * g.ldc + 32) * sizeof(float);
+        const size_t lds = ((size_t)16 * g.ldc + 128) * sizeof(float);
         static bool attr_mw = false;
         if (!attr_mw) {
             DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             attr_mw = true;
         }
-        hipLaunchKernelGGL(jacobi_mw_kernel, dim3(g.nbe / 2), dim3(64), lds, s, g);
+        hipLaunchKernelGGL(jacobi_mw_kernel, dim3(g.nbe / 2), dim3(JMW_T), lds, s, g);
     } else {
         hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, col_stride(n), evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);
     }
