@@ -465,7 +465,7 @@ def main():
     sq = committed_profile("r3_pmc_sq.json") or committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
     mfma_busy = None
     try:
-        mfma_busy = sq["kernels"]["syrk_rda_kernel"]["mfma_util"]      # committed --pmc pass of this command (tools/collect_sq.sh)
+        mfma_busy = sq["kernels"]["syrk_planes_kernel"]["mfma_util"]   # committed --pmc pass of this command (tools/collect_sq.sh)
     except Exception:
         pass
     # per pair-row 2F^2 + 2Fr flops (projection + gradient, dense)
@@ -504,15 +504,19 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "grad_syrk_rda (fused weighted SYRK + dual average)",
+            "kernel": "grad_syrk_rda (fused weighted SYRK + dual average: syrk_split_rows_kernel + syrk_planes_kernel, both inside the timed launch)",
             "achieved": ach_exec,
             "peak": peak_mfma,
             "unit": "TFLOP/s",
             "frac": (ach_exec / peak_mfma) if ach_exec else None,
-            "note": "achieved = flops the matrix cores EXECUTE per launch (the tiles on or above the diagonal, K = rows with a non-zero "
-                    "violation count) / the launch's HIP-event time: a utilisation.  algorithmic_* is SURVEY 8(d)'s dense accounting "
-                    "(2*K*F^2 per launch, no symmetry credit) over the same time; it exceeds the executed figure by ~2x because the "
-                    "kernel never computes the lower triangle, and is NOT a utilisation",
+            "note": "achieved = fp32 flops of the result the launch EXECUTES (the tiles on or above the diagonal, K = rows with a non-zero "
+                    "violation count) / the launch's HIP-event time, against the fp32 MFMA peak the contract names for dtype f32.  The fp32 "
+                    "results come from the bf16 matrix cores (operands split three ways, six bf16 MFMAs per fp32 product term), so the figure "
+                    "can pass 1.0: bf16_mfma_frac prices the same launch as the bf16 MFMA work it issues (6 x executed flops) against the "
+                    "2500 TFLOP/s bf16 peak, and mfma_busy_frac_pmc is the matrix pipe's busy share from the committed PMC pass.  "
+                    "algorithmic_* is SURVEY 8(d)'s dense accounting (2*K*F^2 per launch, no symmetry credit) over the same time; it exceeds "
+                    "the executed figure by ~2x because the kernel never computes the lower triangle, and is NOT a utilisation",
+            "bf16_mfma_frac": (None if args.bf16 or not ach_exec else 6.0 * ach_exec / 2500.0),
             "algorithmic_achieved": ach,
             "algorithmic_frac": (ach / peak_mfma) if ach else None,
             "traffic": traffic,

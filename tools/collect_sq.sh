@@ -15,7 +15,7 @@ d, out = sys.argv[1:3]
 R = os.environ.get("DLCO_ROUND", "r3")
 f = glob.glob(d + "/*/*counter_collection.csv")[0]
 rows = list(csv.DictReader(open(f)))
-want = {"syrk_rda": "syrk_rda_kernel", "skinny_sym_kernel<3, 2>": "skinny_sym_kernel<3,2>", "skinny_sym_kernel<3, 3>": "skinny_sym_kernel<3,3>",
+want = {"syrk_planes_kernel": "syrk_planes_kernel", "syrk_split_rows_kernel": "syrk_split_rows_kernel", "jacobi_mw_kernel": "jacobi_mw_kernel", "skinny_sym_kernel<3, 2>": "skinny_sym_kernel<3,2>", "skinny_sym_kernel<3, 3>": "skinny_sym_kernel<3,3>",
         "jacobi_blk_kernel": "jacobi_blk_kernel", "chol_inv2_kernel": "chol_inv2_kernel", "project_rows_kernel": "project_rows_kernel"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
