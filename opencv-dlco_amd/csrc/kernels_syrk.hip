@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(Syrk
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float *rowb = ctile + (long)(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2)) * cld + wn * 64 + b * 32;
-            dst[r] = rowb[old_lane];
+            dst[r] = __builtin_nontemporal_load(rowb + old_lane);          // streamed once: keep the L2 for the planes
         }
     };
     constexpr int DEPTH = NST - 1;                            // K blocks requested ahead of the one being multiplied
@@ -458,13 +458,13 @@ __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(Syrk
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int il = il0 + e;
-                        if (il <= jl) ctile[(long)il * cld + jl] = o[e];
-                        if (il < jl) ctile[(long)jl * cld + il] = o[e];
+                        if (il <= jl) __builtin_nontemporal_store(o[e], &ctile[(long)il * cld + jl]);
+                        if (il < jl) __builtin_nontemporal_store(o[e], &ctile[(long)jl * cld + il]);
                     }
                 } else {
                     if (!SLAB && !PACKED) *reinterpret_cast<f32x4 *>(&g.C[(long)(j0 + jl) * g.ldc + (i0 + il0)]) = o;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) ctile[(long)(il0 + e) * cld + jl] = o[e];
+                    for (int e = 0; e < 4; e++) __builtin_nontemporal_store(o[e], &ctile[(long)(il0 + e) * cld + jl]);
                 }
             }
         }
