@@ -40,6 +40,43 @@ __global__ void sqdist_kernel(const float *proj, int split, int r, int n, long l
     dist[j] = d;
 }
 
+// The same for a projection that arrives as `split` K-slice slabs (the bf16 variant's batch projection: 32 slices): one
+// thread per column would add split * r values one after the other (1 ms at 32 x 61).  A workgroup takes 64 columns; eight
+// groups of 64 threads sum the slices (in slice order) of eight rows q at a time into LDS, then the first 64 threads add
+// the squares row after row - the same two orders as above.
+__global__ __launch_bounds__(512) void sqdist_split_kernel(const float *proj, int split, int r, int n, long ld, float *dist)
+{
+    __shared__ float p[96][64];
+    const int jl = threadIdx.x & 63, qg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const long plane = (long)r * ld;
+    float d = 0.f;
+    for (int q0 = 0; q0 < r; q0 += 96) {
+        const int qn = min(96, r - q0);
+        for (int q = qg; q < qn; q += 8) {
+            float acc = 0.f;
+            if (j < n) {
+                const float *src = proj + (long)(q0 + q) * ld + j;
+                int z = 0;
+                for (; z + 8 <= split; z += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = src[(z + u) * plane];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc += v[u];
+                }
+                for (; z < split; z++) acc += src[z * plane];
+            }
+            p[q][jl] = acc;
+        }
+        __syncthreads();
+        if (qg == 0)
+            for (int q = 0; q < qn; q++) d += p[q][jl] * p[q][jl];
+        __syncthreads();
+    }
+    if (qg == 0 && j < n) dist[j] = d;
+}
+
 // V1 (src/pj-learn.cpp:373-376): strict (pd_i + 1.0f) > nd_j
 __global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa)
 {
@@ -268,7 +305,8 @@ __global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, cons
 void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(sqdist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, proj, split, r, n, ld, dist);
+    if (split > 2) hipLaunchKernelGGL(sqdist_split_kernel, dim3((n + 63) / 64), dim3(512), 0, s, proj, split, r, n, ld, dist);
+    else hipLaunchKernelGGL(sqdist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, proj, split, r, n, ld, dist);
     DLCO_HIP(hipGetLastError());
 }
 

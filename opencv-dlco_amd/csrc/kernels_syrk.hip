@@ -11,9 +11,9 @@
 // super-blocks so that neighbouring tiles share their row panels in one L2).  fp32 results come by
 // default from the bf16 matrix cores: the active rows are split three ways ONCE (syrk_split_rows_kernel)
 // and a pure matrix kernel fed by LDS-DMA multiplies the planes (syrk_planes_kernel, below).  The older
-// kernel that gathers inside the tile loop (syrk_rda_kernel8) remains for the two other arithmetics:
-// v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain (DLCO_SYRK_FP32=1), and operands rounded to bf16 once
-// (cfg.grad_bf16, BASELINE configs[4]).  Epilogue everywhere: dual-average update in registers.
+// kernel that gathers inside the tile loop (syrk_rda_kernel8) remains for v_mfma_f32_32x32x2_f32, a k-ordered
+// fmaf chain (DLCO_SYRK_FP32=1); operands rounded to bf16 once (cfg.grad_bf16, BASELINE configs[4]) go through
+// the same two new kernels (syrk_round_rows_kernel).  Epilogue everywhere: dual-average update in registers.
 #include "dlco_internal.hpp"
 
 #include <mutex>
@@ -310,10 +310,45 @@ __global__ __launch_bounds__(256) void syrk_split_rows_kernel(const float *D, lo
     }
 }
 
-template <bool SLAB, bool PACKED, int NST>
+// The bf16-once arithmetic (cfg.grad_bf16, BASELINE configs[4]: operands rounded to bf16 once, fp32 accumulation) through the
+// same two kernels: the image's three plane slots hold three consecutive 16-row sub-blocks of a 48-row K block (hi parts
+// only), and the tile kernel multiplies slot s of A with slot s of B - three MFMAs per accumulator and K block instead of six.
+__global__ __launch_bounds__(256) void syrk_round_rows_kernel(const float *D, long ldd, const int32_t *ids, const int32_t *ids2,
+                                                              const float *w, const int *k_dev, int kmax, int nt, char *planes)
+{
+    const int ct = blockIdx.x, kb = blockIdx.y;
+    const int kact = min(*k_dev, kmax);
+    if (kb * 3 * PL_KD >= kact) return;
+    const int col = threadIdx.x & (TB - 1), lk = threadIdx.x >> 7;
+    const int nkb = kmax / PL_KD;                              // (the buffer is sized for 16-row blocks; a third of them are used)
+#pragma unroll
+    for (int sb = 0; sb < 3; sb++) {
+        bf16x8 e[2];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = (kb * 3 + sb) * PL_KD + 8 * lk + j;
+            float v = 0.f, wv = 0.f;
+            if (k < kmax) {                                      // rows in [kact, kmax) are zero-weight padding of the list
+                v = D[(long)ids[k] * ldd + ct * TB + col];
+                if (ids2) v -= D[(long)ids2[k] * ldd + ct * TB + col];
+                wv = w[k];
+            }
+            e[0][j] = (__bf16)(v * wv);
+            e[1][j] = (__bf16)v;
+        }
+#pragma unroll
+        for (int op = 0; op < 2; op++) {
+            bf16x8 *img = reinterpret_cast<bf16x8 *>(planes + (((long)op * nkb + kb) * nt + ct) * PL_IMG);
+            img[(sb * 2 + lk) * TB + col] = e[op];
+        }
+    }
+}
+
+template <bool SLAB, bool PACKED, int NST, bool ONCE = false>
 __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(SyrkDev g, const char *planes)
 {
     constexpr int PL_NSTAGE = NST;
+    constexpr int KD = ONCE ? 3 * PL_KD : PL_KD;               // K rows per image (see syrk_round_rows_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long tr0 = g.trace ? wall_clock64() : 0ull;
     const int ntiles = SLAB ? g.nt * g.slab_nt : g.nt * (g.nt + 1) / 2;
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(Syrk
     const int wm = wave >> 1, wn = wave & 1;                  // rows wm*64.., columns wn*64.. of the tile
     const int lr = lane & 31, lk = lane >> 5;
     const int kact = min(*g.k_dev, g.kmax);
-    const int nk = (kact + PL_KD - 1) / PL_KD;
+    const int nk = (kact + KD - 1) / KD;
     const int nkb = g.kmax / PL_KD;
 
     // this wave's six pieces (1 KB each) of a stage: waves 0, 1 bring the A image (w x of tile row bi), waves 2, 3 the B image
@@ -403,12 +438,18 @@ __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(Syrk
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                if constexpr (ONCE) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][2], acc[a][b], 0, 0, 0);
+                } else {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                }
             }
         // issue order inside the iteration: fragment reads first, then the six DMA pieces spread between the MFMAs (a piece
         // costs the wave ~60 cycles of issue; between two MFMAs that is time the matrix pipe spends on the MFMA before)
@@ -418,7 +459,7 @@ __global__ __launch_bounds__(NTP, NST == 2 ? 3 : 2) void syrk_planes_kernel(Syrk
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
             for (int u = 0; u < 6; u++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, ONCE ? 1 : 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
         }
@@ -640,10 +681,11 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     // once (cfg.grad_bf16, the configs[4] variant)
     static const bool exact_fp32 = std::getenv("DLCO_SYRK_FP32") != nullptr;
     const int prec = bf16 ? 1 : (exact_fp32 ? 0 : 3);
-    if (prec == 3) {
-        // split once, then the matrix kernel (see syrk_planes_kernel)
+    if (prec == 3 || prec == 1) {
+        // split (or round) once, then the matrix kernel (see syrk_planes_kernel)
         char *planes = syrk_planes_buffer((size_t)2 * (kmax / PL_KD) * g.nt * PL_IMG);
-        hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
+        if (prec == 3) hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
+        else hipLaunchKernelGGL(syrk_round_rows_kernel, dim3(g.nt, (kmax + 3 * PL_KD - 1) / (3 * PL_KD)), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         // three stages of 24 KB, two workgroups per CU.  (Two stages and three workgroups per CU - twelve waves - measured
         // the same: 0.133 against 0.132 ms per launch.  What the launch loses is spread over the K loop, where two
         // workgroups sharing a CU reach 72 % of the matrix rate, the 5 us of a tile's 23 outside the loop - first
@@ -654,27 +696,28 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
             DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
             DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
             DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
+            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
             attr = true;
         }
-        if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+        if (prec == 1) {
+            if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true, NST, true>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+            else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false, NST, true>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+            else hipLaunchKernelGGL((syrk_planes_kernel<false, false, NST, true>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
+        } else if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
         else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
         else hipLaunchKernelGGL((syrk_planes_kernel<false, false, NST>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
         DLCO_HIP(hipGetLastError());
         if (tracing) syrk_dump_trace(trace_path, trace_buf, ntiles, s);
         return true;
     }
-#define DLCO_SYRK_LAUNCH(P, S, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, H>), dim3(ntiles), dim3(NT8), 0, s, g)
-#define DLCO_SYRK_LAUNCH_PK(P, H) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, H, true>), dim3(ntiles), dim3(NT8), 0, s, g)
-    if (packed) {
-        if (prec == 1) { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 1); else DLCO_SYRK_LAUNCH_PK(false, 1); }
-        else { if (ids2) DLCO_SYRK_LAUNCH_PK(true, 0); else DLCO_SYRK_LAUNCH_PK(false, 0); }
-    } else if (prec == 1) {
-        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 1); else DLCO_SYRK_LAUNCH(false, true, 1); }
-        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 1); else DLCO_SYRK_LAUNCH(false, false, 1); }
-    } else {
-        if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true, 0); else DLCO_SYRK_LAUNCH(false, true, 0); }
-        else { if (ids2) DLCO_SYRK_LAUNCH(true, false, 0); else DLCO_SYRK_LAUNCH(false, false, 0); }
-    }
+    // prec == 0: the gathering kernel with v_mfma_f32_32x32x2_f32
+#define DLCO_SYRK_LAUNCH(P, S) hipLaunchKernelGGL((syrk_rda_kernel8<P, S, 0>), dim3(ntiles), dim3(NT8), 0, s, g)
+#define DLCO_SYRK_LAUNCH_PK(P) hipLaunchKernelGGL((syrk_rda_kernel8<P, false, 0, true>), dim3(ntiles), dim3(NT8), 0, s, g)
+    if (packed) { if (ids2) DLCO_SYRK_LAUNCH_PK(true); else DLCO_SYRK_LAUNCH_PK(false); }
+    else if (slab) { if (ids2) DLCO_SYRK_LAUNCH(true, true); else DLCO_SYRK_LAUNCH(false, true); }
+    else { if (ids2) DLCO_SYRK_LAUNCH(true, false); else DLCO_SYRK_LAUNCH(false, false); }
 #undef DLCO_SYRK_LAUNCH_PK
 #undef DLCO_SYRK_LAUNCH
     DLCO_HIP(hipGetLastError());

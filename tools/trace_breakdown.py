@@ -2,7 +2,7 @@ import csv, collections, glob, re, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rows = list(csv.DictReader(open(f)))
-syrk = [r for r in rows if 'syrk_split_rows' in r['Kernel_Name']]      # first kernel of a step's gradient
+syrk = [r for r in rows if 'syrk_split_rows' in r['Kernel_Name'] or 'syrk_round_rows' in r['Kernel_Name']]      # first kernel of a step's gradient
 start = int(syrk[-nsteps]['Start_Timestamp'])
 # the timed region ends with the last step's W emission; what follows (the LogStep block that
 # bench.py runs after timing) is not part of it
