@@ -687,7 +687,7 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         if (prec == 3) hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         else hipLaunchKernelGGL(syrk_round_rows_kernel, dim3(g.nt, (kmax + 3 * PL_KD - 1) / (3 * PL_KD)), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         // three stages of 24 KB, two workgroups per CU.  (Two stages and three workgroups per CU - twelve waves - measured
-        // the same: 0.133 against 0.132 ms per launch.  What the launch loses is spread over the K loop, where two
+        // the same: 0.133 against 0.132 ms per launch; so did eight waves of 64 x 32 per tile: 0.137 against 0.133.  What the launch loses is spread over the K loop, where two
         // workgroups sharing a CU reach 72 % of the matrix rate, the 5 us of a tile's 23 outside the loop - first
         // pieces, old tile, stores - and the last of its 4.06 rounds.)
         constexpr int NST = 3;
