@@ -271,7 +271,12 @@ void EigTracker::project_out(float *Wp, int np, const float *Q, int kept)
 // here synchronises with the host and no row is dropped (dependent rows become zero rows).
 int EigTracker::orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends)
 {
-    row_normalize(Z, F_, rows, F_, s_);
+    // One panel (the steady state): Cholesky QR is invariant under a scaling of the rows - the Gram entries keep their
+    // relative accuracy, the dead-row rule compares a pivot with the row's own diagonal entry - so the rows go in as the
+    // filter left them.  With several panels the rows are normalised first: the Gram-Schmidt step between panels zeroes
+    // what is left of a row after projection against a threshold that assumes unit rows.
+    const bool one_panel = rows <= CHOL_INV_MAX_N && (panel_ends.empty() || panel_ends[0] >= rows);
+    if (!one_panel) row_normalize(Z, F_, rows, F_, s_);
     size_t pi = 0;
     for (int p0 = 0; p0 < rows;) {
         while (pi < panel_ends.size() && panel_ends[pi] <= p0) pi++;
