@@ -349,9 +349,8 @@ void step_grad(dlco_ctx *c)
     const int B = c->B, Bl = c->Bl, world = c->cfg.world;
     (void)world;
     gather_dists(c, &c->pd_cur, &c->nd_cur);
-    viol_counts(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->stream);
-    build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, c->lo, c->lo + Bl, c->act_ids.p,
-                      c->act_w.p, c->k_active.p, c->stream);
+    viol_counts_active_rows(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->pos_rows.p, c->neg_rows.p, c->lo, c->lo + Bl,
+                            c->act_ids.p, c->act_w.p, c->k_active.p, c->stream);
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
     if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed);
@@ -408,9 +407,8 @@ void step_sharded(dlco_ctx *c)
     allgather(c, DLCO_BUF_DIST, (size_t)2 * c->Bl * sizeof(float));
     const int B = c->B;
     gather_dists(c, &c->pd_cur, &c->nd_cur);
-    viol_counts(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->stream);
-    build_active_rows(c->pos_rows.p, c->neg_rows.p, c->rho.p, c->kappa.p, B, 0, B, c->act_ids.p, c->act_w.p, c->k_active.p,
-                      c->stream);
+    viol_counts_active_rows(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->pos_rows.p, c->neg_rows.p, 0, B, c->act_ids.p,
+                            c->act_w.p, c->k_active.p, c->stream);
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
     grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * B, alpha, beta, c->dfavg.p);

@@ -199,6 +199,9 @@ void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float
 // rho/kappa + signed weights + compact active list for one batch
 //   pd, nd: [B] distances; out rho[B], kappa[B]; weights[2B] (rho_i for positives, -kappa_j for negatives)
 void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, hipStream_t s);
+// viol_counts + build_active_rows in one launch
+void viol_counts_active_rows(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
+                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s);
 // build the stacked weighted row list of the SYRK: ids[2B] = (pos rows, neg rows), w[2B] = (rho, -kappa);
 // rows with zero weight are dropped; *k_active receives the count. [lo,hi) selects the slots owned by a rank.
 void build_active_rows(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho, const int32_t *kappa,

@@ -78,9 +78,8 @@ __global__ __launch_bounds__(512) void sqdist_split_kernel(const float *proj, in
 }
 
 // V1 (src/pj-learn.cpp:373-376): strict (pd_i + 1.0f) > nd_j
-__global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa)
+__device__ __forceinline__ void viol_body(float *sh, const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa)
 {
-    extern __shared__ float sh[];
     float *spd = sh, *snd = sh + B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) { spd[i] = pd[i] + 1.0f; snd[i] = nd[i]; }
     __syncthreads();
@@ -95,10 +94,15 @@ __global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rh
         kappa[i] = k;
     }
 }
+__global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa)
+{
+    extern __shared__ float sh[];
+    viol_body(sh, pd, nd, B, rho, kappa);
+}
 
 // stacked, weighted, compacted row list of the gradient SYRK (slots [lo,hi) of each class)
-__global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
-                                   const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
+__device__ __forceinline__ void active_rows_body(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
+                                                 const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
 {
     // ordered stream compaction of the 2*(hi-lo) candidates (positives first) by one workgroup:
     // chunk-wise ballot + prefix over the waves keeps the output order equal to the slot order
@@ -135,6 +139,21 @@ __global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_r
     if (tid == 0) *k_active = k;
     // zero padding up to the next multiple of 32 entries: the SYRK consumes whole K tiles
     for (int z = k + tid; z < ((2 * B + 31) & ~31); z += blockDim.x) { ids[z] = 0; w[z] = 0.f; }
+}
+__global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
+                                   const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
+{
+    active_rows_body(pos_rows, neg_rows, rho, kappa, B, lo, hi, ids, w, k_active);
+}
+// V1 and the row list in one launch (the step's own sequence: one workgroup does both anyway)
+__global__ void viol_active_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
+                                   const int32_t *neg_rows, int lo, int hi, int32_t *ids, float *w, int *k_active)
+{
+    extern __shared__ float sh[];
+    viol_body(sh, pd, nd, B, rho, kappa);
+    __threadfence_block();
+    __syncthreads();
+    active_rows_body(pos_rows, neg_rows, rho, kappa, B, lo, hi, ids, w, k_active);
 }
 
 // H1 (src/kernelop-opencv.cu:49-66): one thread per positive row, the inner sum runs over the
@@ -315,6 +334,16 @@ void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t 
     if (B <= 0) return;
     DLCO_CHECK(B <= 8192, -2, "viol_counts: batch too large for one workgroup's LDS");
     hipLaunchKernelGGL(viol_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), s, pd, nd, B, rho, kappa);
+    DLCO_HIP(hipGetLastError());
+}
+
+void viol_counts_active_rows(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
+                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s)
+{
+    if (B <= 0) return;
+    DLCO_CHECK(B <= 8192, -2, "viol_counts: batch too large for one workgroup's LDS");
+    hipLaunchKernelGGL(viol_active_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), s, pd, nd, B, rho, kappa, pos_rows, neg_rows, slot_lo,
+                       slot_hi, ids, w, k_active);
     DLCO_HIP(hipGetLastError());
 }
 
