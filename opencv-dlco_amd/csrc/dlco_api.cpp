@@ -543,6 +543,19 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
         c->eig->set_readback_extra(c->k_active.p);
+        // a growing block takes half of its new rows from the END of the step's active list (the negatives: the positive
+        // eigen-directions of H = -dfAvg come from their outer products).  Every rank must add the same rows, so only
+        // where the list is the global one: a single rank, or the sharded layout.
+        if (c->cfg.world == 1 || c->shard) {
+            c->eig->set_growth_rows([c](float *dst, int want) -> int {
+                const int k = c->eig->readback_extra();          // this step's active row count (rode in with the Ritz block)
+                const int cnt = std::min(want, k);
+                if (cnt <= 0) return 0;
+                const RowRef rr = rows_of(c, c->act_ids.p + (k - cnt), 0, cnt);
+                scale_rows(dst, c->F, c->dists, c->F, nullptr, rr.a, cnt, c->F, c->stream, rr.b);
+                return cnt;
+            });
+        }
         c->dscal.alloc(4);
         // column-sharded dual average (world > 1, or forced for single-rank testing of the path)
         c->shard = cfg->shard != 0 && (cfg->world > 1 || std::getenv("DLCO_FORCE_SHARD") != nullptr);

@@ -564,7 +564,12 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         // ---- grow the block when the positive eigenspace reaches into the guard ------------------
         if (m_ < F_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {
             const int add = std::min(cap_ - m_, std::max(guard_, nw / 4));
-            append_random(Q_, m_, add);
+            // half of the new rows from the caller's source (rows of the step's batch), the rest random: the directions
+            // that have just risen above mu lie mostly in the span of recent batch rows, and a block that starts there
+            // needs fewer passes than one that starts from noise; the random half keeps the block able to find the rest
+            int got = 0;
+            if (grow_cb_) got = std::max(0, std::min(add / 2, grow_cb_(Q_ + (size_t)m_ * F_, add / 2)));
+            append_random(Q_, m_ + got, add - got);
             for (int i = m_; i < m_ + add; i++) { h_theta_[i] = block_min; h_res_[i] = 0.f; }
             m_ += add;
             conv = false;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include "dlco_internal.hpp"
 
+#include <functional>
 #include <initializer_list>
 
 namespace dlco {
@@ -48,6 +49,10 @@ public:
     // One device int the caller wants read back with every Ritz block (the step's active row count): it rides in the
     // block's read-back instead of a copy of its own.  readback_extra() is its value as of the last update().
     void set_readback_extra(const int *dev) { extra_dev_ = dev; }
+    // Where a growing block takes new directions from: the callback writes up to `want` rows (row stride F, on the
+    // tracker's stream) and returns how many it wrote; what it does not provide is filled with random vectors.  The
+    // trainer passes rows of the step's batch: the directions that enter the dual average come from their span.
+    void set_growth_rows(std::function<int(float *dst, int want)> cb) { grow_cb_ = std::move(cb); }
     int readback_extra() const { return extra_val_; }
     void set_packed(bool on) { packed_ = on; }
     bool packed() const { return packed_; }
@@ -71,6 +76,7 @@ private:
 
     int F_, cap_, guard_, max_iter_;
     float tol_;
+    std::function<int(float *, int)> grow_cb_;
     const int *extra_dev_ = nullptr;
     int extra_val_ = 0;
     bool packed_ = false;
