@@ -66,6 +66,7 @@ struct dlco_ctx {
     size_t proj_slab_floats = 0;
     int phase = 0;                   // 0 idle, 1 after begin, 2 after grad
     EigTracker *eig = nullptr;
+    DevBuf<char> syrk_planes;                 // the gradient's split row planes (kernels_syrk.hip): one workspace per context
     RocWork *roc = nullptr;
     int64_t nonconv_steps = 0, steps_run = 0, active_rows_sum = 0;
     int32_t nonconv_window = 0;      // non-converged steps since the last dlco_log_step
@@ -273,8 +274,11 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
     if (c->F % 128 == 0 && (reinterpret_cast<uintptr_t>(c->dists) & 15) == 0 &&
         (!c->shard || (c->comm.c0 % 128 == 0 && c->comm.cw % 128 == 0))) {
         c->prof.begin(PROF_GRAD_SYRK);
+        const size_t pbytes = syrk_planes_bytes(kpad, c->F);
+        if (pbytes > c->syrk_planes.n) { sync(c); c->syrk_planes.alloc(pbytes); }
         const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream,
-                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0, packed);
+                                       c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0, packed,
+                                       c->syrk_planes.p);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;

@@ -169,9 +169,12 @@ bool project_rows_slab(const float *W, long ldw, int r, const float *D, long ldd
 void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s);
 // packed = true: C holds the packed upper tiles (syrk_packed_floats(F) floats, ldc ignored): tile (bi, bj), bi <= bj, is a
 // contiguous row-major 128 x 128 block at tile index bi*nt - bi*(bi-1)/2 + (bj - bi); no mirrored store.
+// planes_ws: >= syrk_planes_bytes(kmax, F) bytes of device memory for the split (or bf16-rounded) row planes of the launch;
+// nullptr: a per-device workspace inside the library (single-stream callers only).
+size_t syrk_planes_bytes(int kmax, int F);
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
-                  int slab_cols = 0, bool bf16 = false, bool packed = false);
+                  int slab_cols = 0, bool bf16 = false, bool packed = false, void *planes_ws = nullptr);
 size_t syrk_packed_floats(int F);
 void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s);      // upper tiles of a full matrix -> packed
 void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s);    // packed -> full symmetric matrix

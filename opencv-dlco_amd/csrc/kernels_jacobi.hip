@@ -753,14 +753,15 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         else if (e == 3) launch_jacobi_blk<3>(T, ldt, n, evals, V, ldv, sweeps_out, stop_cos, lam_cut, s);
         else launch_jacobi_blk<5>(T, ldt, n, evals, V, ldv, sweeps_out, stop_cos, lam_cut, s);
     } else if (n <= JMW_MAX_N) {
-        // many CUs, one wave per block pair; the grid barrier's words sit behind the work image and are cleared per call
+        // many CUs, one workgroup per block pair; the grid barrier's words sit behind the work image and are cleared per call
         JmwDev g;
         g.T = T; g.ldt = ldt; g.n = n; g.evals = evals; g.Vout = V; g.ldv = ldv;
         g.ldc = jmw_ldc(n); g.nbe = jmw_nbe(n);
         const size_t ncol = 8 * (size_t)g.nbe;
         g.G = work; g.lam = work + ncol * g.ldc;
-        static unsigned *sync_words = nullptr;                  // 64 words: counter, flag, per-sweep maxima
-        if (!sync_words) DLCO_HIP(hipMalloc((void **)&sync_words, 64 * sizeof(unsigned)));
+        // 64 words behind the image and the two vectors (counter, flag, per-sweep maxima), cleared per call: they belong to
+        // the caller's workspace, so two trackers on two streams never share a barrier
+        unsigned *sync_words = reinterpret_cast<unsigned *>(work + ncol * g.ldc + 2 * ncol);
         DLCO_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
         g.sync = sync_words; g.sweeps_out = sweeps_out; g.stop_cos = stop_cos; g.lam_cut = lam_cut;
         const size_t lds = ((size_t)16 * g.ldc + 128) * sizeof(float);

@@ -623,7 +623,9 @@ static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count
 }
 
 
-// Workspace of the split planes: one per device, grown on demand (2 operands x 6 bytes per staged value).
+size_t syrk_planes_bytes(int kmax, int F) { return (size_t)2 * (kmax / PL_KD) * (F / TB) * PL_IMG; }
+
+// Workspace of the split planes for callers that bring none: one per device, grown on demand (2 operands x 6 bytes per staged value).
 static char *syrk_planes_buffer(size_t bytes)
 {
     struct Entry { int dev; char *p; size_t cap; };
@@ -651,7 +653,7 @@ static char *syrk_planes_buffer(size_t bytes)
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16,
-                  bool packed)
+                  bool packed, void *planes_ws)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
     const bool slab = slab_cols > 0;
@@ -683,7 +685,9 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
     const int prec = bf16 ? 1 : (exact_fp32 ? 0 : 3);
     if (prec == 3 || prec == 1) {
         // split (or round) once, then the matrix kernel (see syrk_planes_kernel)
-        char *planes = syrk_planes_buffer((size_t)2 * (kmax / PL_KD) * g.nt * PL_IMG);
+        // the caller's workspace (a context owns one: launches of two contexts on two streams must not share planes), or
+        // the per-device one for callers without (developer tools: one stream)
+        char *planes = planes_ws ? static_cast<char *>(planes_ws) : syrk_planes_buffer(syrk_planes_bytes(kmax, F));
         if (prec == 3) hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         else hipLaunchKernelGGL(syrk_round_rows_kernel, dim3(g.nt, (kmax + 3 * PL_KD - 1) / (3 * PL_KD)), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         // three stages of 24 KB, two workgroups per CU.  (Two stages and three workgroups per CU - twelve waves - measured
