@@ -81,8 +81,7 @@ def build_context(dlco, wl, B=None, device=0, rank=0, world=1, shard=0, data_fro
     ctx = dlco.Context(wl["F"], wl["N"], B=B or wl["batch"], mu=wl["mu"], gamma=wl["gamma"], device=device, rank=rank,
                        world=world, shard=shard, **kw)
     if data_from is not None:
-        ptr, _ = data_from.dev_buffer(dlco.BUF_DATA)
-        ctx.set_data_device(ptr, (np.arange(wl["N"]) % 2 == 0).astype(np.uint8))
+        ctx.set_data_shared(data_from)
     else:
         ctx.synth_data(make_U(wl["F"], wl["latent"], wl["seed"]), wl["seed"], wl["sigma_pos"], wl["sigma_neg"],
                        wl["noise"], wl["jitter"])

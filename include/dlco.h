@@ -89,9 +89,21 @@ int dlco_device_name(const dlco_ctx *ctx, char *buf, size_t cap, int *cc_major, 
 /* Uploads Distance [N,F] row-major f32 and Label [N] u8 (1 = match, 0 = non-match) to HBM,
  * builds IdxPos/IdxNeg, shuffles and splits them.  Replaces src/pj-learn.cpp:214-256,277-281. */
 int dlco_set_data(dlco_ctx *ctx, const float *dists_host, const uint8_t *labels_host);
-/* Same, but `dists_dev` already lives in device memory and is adopted, not copied
- * (it must stay valid for the life of the context). */
+/* Same, but `dists_dev` [N,F] (row stride F) already lives in device memory.  When F is a multiple of the
+ * device width's granularity (dlco_device_width(ctx) == F) it is adopted, not copied, and must stay valid
+ * for the life of the context; otherwise it is copied once into the padded resident layout. */
 int dlco_set_data_device(dlco_ctx *ctx, const float *dists_dev, const uint8_t *labels_host);
+/* FeatDim is whatever the input file says (src/pj-learn.cpp:176-179: 480, 544, 608 in the reference's own
+ * runs).  On the device every row is kept at dlco_device_width(ctx) floats: F rounded up to whole 128-column
+ * tiles (to 128*world when the dual average is column-sharded), the extra columns zero.  Zero columns add
+ * zero rows and columns to the dual average; their eigenvalue of A = -c (dfAvg + mu I) is -c mu <= 0 and is
+ * never kept (src/pj-learn.cpp:452,480-484), so W, A, dfAvg, distances and statistics restricted to the
+ * first F columns are those of the unpadded computation.  Every host-side argument and result of this
+ * header has the caller's width F; only DLCO_BUF_* device buffers show the padded width. */
+int dlco_device_width(const dlco_ctx *ctx);
+/* The resident matrix (row or pair mode, labels, pair index) of another context on the same device with the
+ * same F and N: shared, not copied (`src` must outlive ctx).  What bench.py's second trainer uses. */
+int dlco_set_data_shared(dlco_ctx *ctx, dlco_ctx *src);
 /* Pair mode: instead of the N x F "Distance" matrix that comp-uprjdists materialises
  * (Dist = Desc1 - Desc2 per pair, src/comp-uprjdists.cpp:308-327; 16 GB for 500k x 8192)
  * the caller uploads the P per-patch descriptors desc_host [P,F] once and the pair table
@@ -140,16 +152,17 @@ int dlco_step_finish(dlco_ctx *ctx);
 
 #define DLCO_BUF_DIST   1   /* f32 [world][2*B/world]: rank g's slice holds the distances of its
                                B/world positive slots, then of its B/world negative slots   */
-#define DLCO_BUF_GRAD   2   /* f32 [F*F]: this rank's dLoss partial                    */
-#define DLCO_BUF_DFAVG  3   /* f32 [F*F]: running dual average.  A single-rank context at F = 8192 keeps only the tiles on
-                               or above the diagonal: 2080 contiguous row-major 128 x 128 blocks, tile (I, J), I <= J, at
-                               block index 64 I - I (I - 1) / 2 + J - I (dlco_get_dfavg / dlco_set_state convert)      */
-#define DLCO_BUF_W      4   /* f32 [r*F]: current projection                           */
+/* (device buffers: F below is the padded device width Fd = dlco_device_width(ctx), not cfg.F) */
+#define DLCO_BUF_GRAD   2   /* f32 [Fd*Fd]: this rank's dLoss partial                  */
+#define DLCO_BUF_DFAVG  3   /* f32 [Fd*Fd]: running dual average.  A single-rank context with Fd <= 8192 keeps only the
+                               nt (nt + 1) / 2 tiles on or above the diagonal (nt = Fd / 128): contiguous row-major
+                               128 x 128 blocks, tile (I, J), I <= J, at block index nt I - I (I - 1) / 2 + J - I
+                               (dlco_get_dfavg / dlco_set_state convert)                                           */
+#define DLCO_BUF_W      4   /* f32 [r*Fd]: current projection                          */
 #define DLCO_BUF_GATHER 5   /* f32 [world][rows*F/world]: column slabs of a tracker product
                                (sharded contexts only)                                   */
-#define DLCO_BUF_DATA   6   /* f32 [N*F] (row mode) or [P*F] (pair mode): the resident Distance /
-                               descriptor matrix, e.g. to share it with a second context through
-                               dlco_set_data_device                                         */
+#define DLCO_BUF_DATA   6   /* f32 [N*Fd] (row mode) or [P*Fd] (pair mode): the resident Distance /
+                               descriptor matrix (dlco_set_data_shared shares it with a second context) */
 /* Device pointer and byte size of an exchange buffer (valid until ctx is destroyed). */
 int dlco_dev_buffer(dlco_ctx *ctx, int32_t which, void **dev_ptr, size_t *bytes);
 /* Makes the context use caller-owned device memory for an exchange buffer (DLCO_BUF_DIST,

@@ -84,6 +84,8 @@ def load():
     L.dlco_device_name.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dlco_set_data.argtypes = [vp, f32p, u8p]
     L.dlco_set_data_device.argtypes = [vp, vp, u8p]
+    L.dlco_set_data_shared.argtypes = [vp, vp]
+    L.dlco_device_width.argtypes = [vp]
     L.dlco_set_pairs.argtypes = [vp, f32p, C.c_int32, i32p]
     L.dlco_synth_data.argtypes = [vp, f32p, C.c_int32, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float]
     L.dlco_get_rows.argtypes = [vp, C.c_int32, C.c_int32, f32p]
@@ -238,6 +240,14 @@ class Context:
     def set_data_device(self, dev_ptr, labels):
         l = np.ascontiguousarray(labels, np.uint8).ravel()
         self._ck(self.L.dlco_set_data_device(self.h, C.c_void_p(dev_ptr), _p(l, u8p)))
+
+    def set_data_shared(self, other):
+        """Train on the resident matrix of another context (same device, F, N): shared, not copied."""
+        self._ck(self.L.dlco_set_data_shared(self.h, other.h))
+
+    def device_width(self):
+        """Row width on the device: F rounded up to whole 128-column tiles (see dlco_device_width)."""
+        return int(self.L.dlco_device_width(self.h))
 
     def set_pairs(self, desc, pairs):
         """Pair mode: per-patch descriptors [P,F] + the [N,4] Indices table (see dlco_set_pairs)."""

@@ -20,7 +20,11 @@ static thread_local std::string g_last_error;
 
 struct dlco_ctx {
     dlco_cfg cfg{};
-    int F = 0, N = 0, B = 0, Bl = 0, lo = 0;
+    // F is the width every device buffer and kernel works at: the caller's FeatDim (Fu, src/pj-learn.cpp:176-179) rounded up
+    // to the 128-column tile of the fused kernels, the extra columns zero.  Zero columns add zero rows / columns to the dual
+    // average, whose eigenvalue in A = -c (dfAvg + mu I) is -c mu <= 0: never kept (src/pj-learn.cpp:452,480-484), so every
+    // result restricted to the first Fu columns is that of the unpadded computation; the ABI converts at its boundary.
+    int F = 0, Fu = 0, N = 0, B = 0, Bl = 0, lo = 0;
     hipStream_t stream = nullptr;
     std::string err;
     hipDeviceProp_t prop{};
@@ -155,6 +159,46 @@ void d2h(dlco_ctx *c, void *dst, const void *src, size_t bytes)
 {
     DLCO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     sync(c);
+}
+
+// rows of the caller's width Fu <-> device rows of the padded width F.  An upload leaves the pad columns alone: the
+// destination was zeroed (or is zeroed here with `zero_pad`) before.
+void h2d_rows(dlco_ctx *c, float *dst_dev, const float *src_host, size_t rows, bool zero_pad = false)
+{
+    if (rows == 0) return;
+    if (c->Fu == c->F) { h2d(c, dst_dev, src_host, rows * c->F * sizeof(float)); return; }
+    if (zero_pad) DLCO_HIP(hipMemsetAsync(dst_dev, 0, rows * c->F * sizeof(float), c->stream));
+    DLCO_HIP(hipMemcpy2DAsync(dst_dev, (size_t)c->F * sizeof(float), src_host, (size_t)c->Fu * sizeof(float),
+                              (size_t)c->Fu * sizeof(float), rows, hipMemcpyHostToDevice, c->stream));
+    sync(c);
+}
+void d2h_rows(dlco_ctx *c, float *dst_host, const float *src_dev, size_t rows)
+{
+    if (rows == 0) return;
+    if (c->Fu == c->F) { d2h(c, dst_host, src_dev, rows * c->F * sizeof(float)); return; }
+    DLCO_HIP(hipMemcpy2DAsync(dst_host, (size_t)c->Fu * sizeof(float), src_dev, (size_t)c->F * sizeof(float),
+                              (size_t)c->Fu * sizeof(float), rows, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+}
+// an Fu x Fu matrix of the caller <-> the leading block of an F x F device matrix (pad rows and columns zero)
+void h2d_square(dlco_ctx *c, float *dst_dev, const float *src_host)
+{
+    if (c->Fu != c->F) DLCO_HIP(hipMemsetAsync(dst_dev, 0, (size_t)c->F * c->F * sizeof(float), c->stream));
+    h2d_rows(c, dst_dev, src_host, (size_t)c->Fu);
+}
+void d2h_square(dlco_ctx *c, float *dst_host, const float *src_dev) { d2h_rows(c, dst_host, src_dev, (size_t)c->Fu); }
+
+// A resident matrix handed over on the device with the caller's row stride Fu: used in place when no padding is needed,
+// else copied once into an own padded allocation.
+const float *adopt_device_rows(dlco_ctx *c, const float *src_dev, size_t rows)
+{
+    if (c->Fu == c->F) return src_dev;
+    c->dists_own.alloc(rows * c->F);
+    DLCO_HIP(hipMemsetAsync(c->dists_own.p, 0, rows * c->F * sizeof(float), c->stream));
+    DLCO_HIP(hipMemcpy2DAsync(c->dists_own.p, (size_t)c->F * sizeof(float), src_dev, (size_t)c->Fu * sizeof(float),
+                              (size_t)c->Fu * sizeof(float), rows, hipMemcpyDeviceToDevice, c->stream));
+    sync(c);
+    return c->dists_own.p;
 }
 
 void finish_data(dlco_ctx *c, const uint8_t *labels_host)
@@ -423,11 +467,11 @@ void step_sharded(dlco_ctx *c)
 void get_W_host(dlco_ctx *c, float *W_host, int32_t *r)
 {
     if (c->r > 0) {
-        if (W_host) d2h(c, W_host, c->W.p, (size_t)c->r * c->F * sizeof(float));
+        if (W_host) d2h_rows(c, W_host, c->W.p, (size_t)c->r);
         if (r) *r = c->r;
     } else {
-        if (W_host) std::memset(W_host, 0, (size_t)c->F * c->F * sizeof(float));   // src/pj-learn.cpp:489-490
-        if (r) *r = c->F;
+        if (W_host) std::memset(W_host, 0, (size_t)c->Fu * c->Fu * sizeof(float));   // src/pj-learn.cpp:489-490
+        if (r) *r = c->Fu;
     }
 }
 
@@ -459,7 +503,7 @@ void validate(dlco_ctx *c, float *loss_val, float *regul, int32_t *rank)
     const float Loss = (float)total;                               // src/pj-learn.cpp:520
     *loss_val = Loss / (float)npv / (float)nnv;                    // :524
     *regul = (float)((double)c->cfg.mu * c->traceA);               // :527, trace(A) = sum of kept eigenvalues
-    if (rank) *rank = c->r > 0 ? c->r : c->F;
+    if (rank) *rank = c->r > 0 ? c->r : c->Fu;
 }
 
 void stats(dlco_ctx *c, const float *Wd, int r, int32_t *dim, float *fpr95, double *auc)
@@ -493,7 +537,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
     *out = nullptr;
     dlco_ctx *c = nullptr;
     int rc = guarded(nullptr, [&] {
-        DLCO_CHECK(cfg->F >= 4 && cfg->F % 4 == 0, DLCO_ERR_INVALID, "F must be a positive multiple of 4");
+        DLCO_CHECK(cfg->F >= 1 && cfg->F <= (1 << 20), DLCO_ERR_INVALID, "F must be positive");
         DLCO_CHECK(cfg->N >= 2 && cfg->B >= 1, DLCO_ERR_INVALID, "N >= 2 and B >= 1 required");
         DLCO_CHECK(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, DLCO_ERR_INVALID, "bad rank/world");
         DLCO_CHECK(cfg->B % cfg->world == 0, DLCO_ERR_INVALID, "B must be divisible by world");
@@ -511,8 +555,15 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         DLCO_HIP(hipGetDeviceProperties(&c->prop, cfg->device));
         if (std::strncmp(c->prop.gcnArchName, "gfx950", 6) != 0)
             throw Error(DLCO_ERR_NODEVICE, std::string("device is ") + c->prop.gcnArchName + ", this build targets gfx950 only");
-        c->F = cfg->F; c->N = cfg->N; c->B = cfg->B;
+        c->Fu = cfg->F; c->N = cfg->N; c->B = cfg->B;
         c->Bl = cfg->B / cfg->world; c->lo = cfg->rank * c->Bl;
+        // column-sharded dual average (world > 1, or forced for single-rank testing of the path)
+        c->shard = cfg->shard != 0 && (cfg->world > 1 || std::getenv("DLCO_FORCE_SHARD") != nullptr);
+        // device width: whole 128-column tiles (whole tiles per rank when the columns are sharded)
+        {
+            const int gran = 128 * (c->shard ? cfg->world : 1);
+            c->F = (c->Fu + gran - 1) / gran * gran;
+        }
         c->rng = CvRng(cfg->seed);
         DLCO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->prof.s = c->stream;
@@ -528,12 +579,12 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const int max_rows = std::max(1024, 2 * cfg->B + 2 * c->cfg.eig_guard);
         // the m x m solver of the Rayleigh-Ritz step (jacobi_eigh) takes at most 4096 rows: a global batch whose
         // block could outgrow that is refused here, not in the middle of a run
-        DLCO_CHECK(std::min(c->F, max_rows) <= 4096, DLCO_ERR_INVALID,
+        DLCO_CHECK(std::min(c->Fu, max_rows) <= 4096, DLCO_ERR_INVALID,
                    "global batch too large for the eigen tracker: 2*B + 2*eig_guard must not exceed 4096 when F > 4096");
-        c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream);
+        c->eig = new EigTracker(c->F, max_rows, c->cfg.eig_guard, c->cfg.eig_tol, c->cfg.eig_max_iter, c->stream, c->Fu);
         c->eig->set_profiler(&c->prof);
         c->eig->set_packed(c->packed);
-        c->w_cap = std::min(c->F, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
+        c->w_cap = std::min(c->Fu, std::max(max_rows, 2 * c->cfg.eig_guard + 32));
         c->W.alloc((size_t)c->w_cap * c->F);
         const int B = c->B;
         c->h_pos_rows.assign(B, 0); c->h_neg_rows.assign(B, 0);
@@ -546,13 +597,18 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
+        c->k_active.zero(c->stream);                              // read back with every Ritz block, also before the first step
         c->eig->set_readback_extra(c->k_active.p);
         // a growing block takes half of its new rows from the END of the step's active list (the negatives: the positive
         // eigen-directions of H = -dfAvg come from their outer products).  Every rank must add the same rows, so only
         // where the list is the global one: a single rank, or the sharded layout.
         if (c->cfg.world == 1 || c->shard) {
             c->eig->set_growth_rows([c](float *dst, int want) -> int {
+                // only inside a training step (phase 2: the active list on the device is this step's); an operator call
+                // (dlco_psd_project) or a context without data grows from random rows alone
+                if (c->phase != 2 || !c->have_data) return 0;
                 const int k = c->eig->readback_extra();          // this step's active row count (rode in with the Ritz block)
+                if (k <= 0 || k > 2 * c->B) return 0;
                 const int cnt = std::min(want, k);
                 if (cnt <= 0) return 0;
                 const RowRef rr = rows_of(c, c->act_ids.p + (k - cnt), 0, cnt);
@@ -561,10 +617,7 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
             });
         }
         c->dscal.alloc(4);
-        // column-sharded dual average (world > 1, or forced for single-rank testing of the path)
-        c->shard = cfg->shard != 0 && (cfg->world > 1 || std::getenv("DLCO_FORCE_SHARD") != nullptr);
         if (c->shard) {
-            DLCO_CHECK(c->F % (4 * cfg->world) == 0, DLCO_ERR_INVALID, "shard: F must be a multiple of 4*world");
             c->comm.world = cfg->world; c->comm.rank = cfg->rank;
             c->comm.cw = c->F / cfg->world; c->comm.c0 = cfg->rank * c->comm.cw;
             c->comm.gather_floats = (size_t)c->w_cap * c->F;
@@ -609,7 +662,7 @@ int dlco_set_data(dlco_ctx *c, const float *dists_host, const uint8_t *labels_ho
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         c->dists_own.alloc((size_t)c->N * c->F);
-        h2d(c, c->dists_own.p, dists_host, (size_t)c->N * c->F * sizeof(float));
+        h2d_rows(c, c->dists_own.p, dists_host, (size_t)c->N, true);
         c->dists = c->dists_own.p;
         c->pair_mode = false;
         finish_data(c, labels_host);
@@ -645,10 +698,10 @@ static int set_pairs(dlco_ctx *c, const float *desc_host, bool desc_on_device, i
             lab[i] = (q[1] == q[3]) ? 1 : 0;                       // src/comp-uprjdists.cpp:268-272
         }
         if (desc_on_device) {
-            c->dists = desc_host;
+            c->dists = adopt_device_rows(c, desc_host, (size_t)P);
         } else {
             c->dists_own.alloc((size_t)P * c->F);
-            h2d(c, c->dists_own.p, desc_host, (size_t)P * c->F * sizeof(float));
+            h2d_rows(c, c->dists_own.p, desc_host, (size_t)P, true);
             c->dists = c->dists_own.p;
         }
         c->pair_a.alloc(c->N); c->pair_b.alloc(c->N);
@@ -664,9 +717,32 @@ int dlco_set_data_device(dlco_ctx *c, const float *dists_dev, const uint8_t *lab
     if (!c || !dists_dev || !labels_host) return DLCO_ERR_INVALID;
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
-        c->dists = dists_dev;
+        c->dists = adopt_device_rows(c, dists_dev, (size_t)c->N);
         c->pair_mode = false;
         finish_data(c, labels_host);
+    });
+}
+
+int dlco_device_width(const dlco_ctx *c) { return c ? c->F : DLCO_ERR_INVALID; }
+
+int dlco_set_data_shared(dlco_ctx *c, dlco_ctx *src)
+{
+    if (!c || !src || c == src) return DLCO_ERR_INVALID;
+    return guarded(c, [&] {
+        DLCO_HIP(hipSetDevice(c->cfg.device));
+        DLCO_CHECK(src->have_data, DLCO_ERR_INVALID, "dlco_set_data_shared: the source context holds no data");
+        DLCO_CHECK(src->cfg.device == c->cfg.device && src->Fu == c->Fu && src->F == c->F && src->N == c->N, DLCO_ERR_INVALID,
+                   "dlco_set_data_shared: device, F (and its padded width) and N must match");
+        c->dists = src->dists;
+        c->pair_mode = src->pair_mode;
+        c->P = src->P;
+        if (src->pair_mode) {                                     // the pair table is small: an own copy
+            c->pair_a.alloc(c->N); c->pair_b.alloc(c->N);
+            DLCO_HIP(hipMemcpyAsync(c->pair_a.p, src->pair_a.p, (size_t)c->N * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            DLCO_HIP(hipMemcpyAsync(c->pair_b.p, src->pair_b.p, (size_t)c->N * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            sync(c);
+        }
+        finish_data(c, src->labels.data());
     });
 }
 
@@ -677,10 +753,11 @@ int dlco_synth_data(dlco_ctx *c, const float *U_host, int32_t k, uint64_t seed, 
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         c->dists_own.alloc((size_t)c->N * c->F);
+        if (c->Fu != c->F) c->dists_own.zero(c->stream);
         DevBuf<float> U;
-        U.alloc((size_t)k * c->F);
-        h2d(c, U.p, U_host, (size_t)k * c->F * sizeof(float));
-        synth_rows(c->dists_own.p, c->N, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, scale_jitter, c->stream);
+        U.alloc((size_t)k * c->Fu);
+        h2d(c, U.p, U_host, (size_t)k * c->Fu * sizeof(float));
+        synth_rows(c->dists_own.p, c->N, c->Fu, c->F, U.p, k, seed, sigma_pos, sigma_neg, noise, scale_jitter, c->stream);
         sync(c);
         c->dists = c->dists_own.p;
         c->pair_mode = false;
@@ -699,10 +776,10 @@ int dlco_get_rows(dlco_ctx *c, int32_t row0, int32_t n, float *out_host)
             DevBuf<float> tmp;
             tmp.alloc((size_t)std::max(n, 1) * c->F);
             scale_rows(tmp.p, c->F, c->dists, c->F, nullptr, c->pair_a.p + row0, n, c->F, c->stream, c->pair_b.p + row0);
-            d2h(c, out_host, tmp.p, (size_t)n * c->F * sizeof(float));
+            d2h_rows(c, out_host, tmp.p, (size_t)n);
             return;
         }
-        d2h(c, out_host, c->dists + (size_t)row0 * c->F, (size_t)n * c->F * sizeof(float));
+        d2h_rows(c, out_host, c->dists + (size_t)row0 * c->F, (size_t)n);
     });
 }
 
@@ -886,7 +963,7 @@ int dlco_get_A(dlco_ctx *c, float *A_host)
     return guarded(c, [&] {
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_A: step in flight");
         build_A(c, c->W.p, c->r);
-        d2h(c, A_host, c->grad.p, (size_t)c->F * c->F * sizeof(float));
+        d2h_square(c, A_host, c->grad.p);
     });
 }
 
@@ -897,10 +974,10 @@ int dlco_get_dfavg(dlco_ctx *c, float *out)
         if (c->packed) {                                         // unpack into the F x F scratch first
             DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_dfavg: step in flight");
             syrk_unpack_upper(c->dfavg.p, c->F, c->grad.p, c->F, c->stream);
-            d2h(c, out, c->grad.p, (size_t)c->F * c->F * sizeof(float));
+            d2h_square(c, out, c->grad.p);
             return;
         }
-        d2h(c, out, c->dfavg.p, (size_t)c->F * c->F * sizeof(float));
+        d2h_square(c, out, c->dfavg.p);
     });
 }
 
@@ -912,21 +989,21 @@ int dlco_set_state(dlco_ctx *c, uint32_t t, const float *dfavg_host, const float
         DLCO_CHECK(r >= 0 && r <= c->w_cap, DLCO_ERR_INVALID, "dlco_set_state: r out of range");
         c->t = t;
         if (dfavg_host && c->packed) {                            // the upper tiles are all that is kept
-            h2d(c, c->grad.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+            h2d_square(c, c->grad.p, dfavg_host);
             syrk_mirror_upper(c->grad.p, c->F, c->F, c->stream);   // (diagonal tiles are stored whole: make them exactly symmetric)
             syrk_pack_upper(c->grad.p, c->F, c->F, c->dfavg.p, c->stream);
         } else if (dfavg_host) {
-            h2d(c, c->dfavg.p, dfavg_host, (size_t)c->F * c->F * sizeof(float));
+            h2d_square(c, c->dfavg.p, dfavg_host);
             if (!c->shard) syrk_mirror_upper(c->dfavg.p, c->F, c->F, c->stream);
         }
         c->eig->reset();
         if (W_host && r > 0) {
-            h2d(c, c->W.p, W_host, (size_t)r * c->F * sizeof(float));
+            h2d_rows(c, c->W.p, W_host, (size_t)r, true);
             c->r = r;
             c->eig->seed_rows(c->W.p, c->F, nullptr, r);
             // trace(A) of the regulariser (src/pj-learn.cpp:527) for this W: trace(W^T W) = |W|_F^2
             double tr = 0.0;
-            for (size_t i = 0; i < (size_t)r * c->F; i++) tr += (double)W_host[i] * (double)W_host[i];
+            for (size_t i = 0; i < (size_t)r * c->Fu; i++) tr += (double)W_host[i] * (double)W_host[i];
             c->traceA = tr;
         } else {
             c->r = 0;
@@ -951,14 +1028,14 @@ int dlco_stats(dlco_ctx *c, const float *W_host, int32_t r, int32_t *dim, float 
         std::vector<float> nz;
         int rows = 0;
         for (int i = 0; i < r; i++) {
-            const float *row = W_host + (size_t)i * c->F;
+            const float *row = W_host + (size_t)i * c->Fu;
             bool any = false;
-            for (int f = 0; f < c->F && !any; f++) any = row[f] != 0.0f;
-            if (any) { nz.insert(nz.end(), row, row + c->F); rows++; }
+            for (int f = 0; f < c->Fu && !any; f++) any = row[f] != 0.0f;
+            if (any) { nz.insert(nz.end(), row, row + c->Fu); rows++; }
         }
         DevBuf<float> Wd;
         Wd.alloc((size_t)std::max(rows, 1) * c->F);
-        if (rows) h2d(c, Wd.p, nz.data(), nz.size() * sizeof(float));
+        if (rows) h2d_rows(c, Wd.p, nz.data(), (size_t)rows, true);
         stats(c, Wd.p, rows, dim, fpr95, auc);
     });
 }
@@ -976,7 +1053,7 @@ int dlco_project_sqdist(dlco_ctx *c, const int32_t *row_ids_host, int32_t n, con
         DevBuf<int32_t> ids; ids.alloc(n);
         DevBuf<float> Wd, out; Wd.alloc((size_t)std::max(r, 1) * c->F); out.alloc(n);
         h2d(c, ids.p, row_ids_host, (size_t)n * sizeof(int32_t));
-        if (r) h2d(c, Wd.p, W_host, (size_t)r * c->F * sizeof(float));
+        if (r) h2d_rows(c, Wd.p, W_host, (size_t)r, true);
         if (n <= 4096) project_few(c, ids.p, n, Wd.p, r, out.p);
         else project_many(c, ids.p, 0, n, Wd.p, r, out.p);
         d2h(c, out_host, out.p, (size_t)n * sizeof(float));
@@ -1019,7 +1096,7 @@ int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_
         h2d(c, kap.p, kappa_host, (size_t)B * sizeof(int32_t));
         const size_t FF = (size_t)c->F * c->F;
         if (dfavg_in_host) {
-            h2d(c, c->grad.p, dfavg_in_host, FF * sizeof(float));
+            h2d_square(c, c->grad.p, dfavg_in_host);
             if (!c->shard) syrk_mirror_upper(c->grad.p, c->F, c->F, c->stream);
         } else fill_f32(c->grad.p, 0.f, FF, c->stream);
         build_active_rows(pr.p, nr.p, rho.p, kap.p, B, 0, B, ids.p, w.p, k.p, c->stream);
@@ -1029,11 +1106,11 @@ int dlco_grad_rda(dlco_ctx *c, const int32_t *pos_rows_host, const int32_t *neg_
             syrk_pack_upper(c->grad.p, c->F, c->F, pk.p, c->stream);
             grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, pk.p, true);
             syrk_unpack_upper(pk.p, c->F, c->grad.p, c->F, c->stream);
-            d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));
+            d2h_square(c, dfavg_out_host, c->grad.p);
             return;
         }
         grad_syrk(c, ids.p, w.p, k.p, 2 * B, alpha, beta, c->grad.p);
-        d2h(c, dfavg_out_host, c->grad.p, FF * sizeof(float));
+        d2h_square(c, dfavg_out_host, c->grad.p);
     });
 }
 
@@ -1046,7 +1123,7 @@ int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_
         const size_t FF = (size_t)c->F * c->F;
         DevBuf<float> G, Gp;
         G.alloc(FF);
-        h2d(c, G.p, dfavg_host, FF * sizeof(float));
+        h2d_square(c, G.p, dfavg_host);
         if (c->packed) {                                         // the tracker of a packed context reads packed tiles
             Gp.alloc(syrk_packed_floats(c->F));
             syrk_mirror_upper(G.p, c->F, c->F, c->stream);
@@ -1061,15 +1138,15 @@ int dlco_psd_project(dlco_ctx *c, const float *dfavg_host, uint32_t t, float *W_
         const int rr = c->eig->update(c->packed ? Gp.p : G.p, c->cfg.mu, cscale, Wd.p, &tr, &conv);
         c->eig->reset();
         if (rr > 0) {
-            if (W_host) d2h(c, W_host, Wd.p, (size_t)rr * c->F * sizeof(float));
+            if (W_host) d2h_rows(c, W_host, Wd.p, (size_t)rr);
             *r = rr;
         } else {
-            if (W_host) std::memset(W_host, 0, FF * sizeof(float));
-            *r = c->F;
+            if (W_host) std::memset(W_host, 0, (size_t)c->Fu * c->Fu * sizeof(float));
+            *r = c->Fu;
         }
         if (A_host) {
             build_A(c, Wd.p, rr);
-            d2h(c, A_host, c->grad.p, FF * sizeof(float));
+            d2h_square(c, A_host, c->grad.p);
         }
         if (!conv) throw Error(DLCO_ERR_NOCONV, "dlco_psd_project: tracker did not reach its tolerance");
     });
@@ -1084,8 +1161,8 @@ int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float
         DevBuf<float> X, G, out;
         X.alloc((size_t)pad * F); G.alloc((size_t)F * F); out.alloc((size_t)pad * F);
         X.zero(c->stream);
-        h2d(c, X.p, X_host, (size_t)rows * F * sizeof(float));
-        h2d(c, G.p, G_host, (size_t)F * F * sizeof(float));
+        h2d_rows(c, X.p, X_host, (size_t)rows);
+        h2d_square(c, G.p, G_host);
         bool ok;
         if (mode == 3 || mode == 4) {                            // packed upper tiles, every tile fetched once
             DevBuf<char> hi, lo, lo2;
@@ -1112,7 +1189,7 @@ int dlco_sym_product(dlco_ctx *c, const float *X_host, int32_t rows, const float
             ok = skinny_product_f32(X.p, F, rows, pad, G.p, F, F, F, 1.0f, out.p, F, nullptr, 0.f, nullptr, 0.f, c->stream);
         }
         DLCO_CHECK(ok, DLCO_ERR_INVALID, "dlco_sym_product: shape not supported by this mode");
-        d2h(c, out_host, out.p, (size_t)rows * F * sizeof(float));
+        d2h_rows(c, out_host, out.p, (size_t)rows);
     });
 }
 
@@ -1174,7 +1251,7 @@ int dlco_log_step(dlco_ctx *c, dlco_log_entry *out)
                 c->auc_best = auc; c->fpr95_best = f95;
                 // W_Save = W.clone(), A_Save = A.clone() (:561-562): the clone is a device copy of the rows of W
                 c->r_save_dev = c->r;
-                c->r_save = c->r > 0 ? c->r : c->F;                  // no positive eigenvalue: W = zeros(F, F), :489-490
+                c->r_save = c->r > 0 ? c->r : c->Fu;                 // no positive eigenvalue: W = zeros(F, F), :489-490
                 if (c->r > 0) {
                     c->W_save_dev.alloc((size_t)c->w_cap * c->F);
                     DLCO_HIP(hipMemcpyAsync(c->W_save_dev.p, c->W.p, (size_t)c->r * c->F * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -1198,14 +1275,13 @@ int dlco_get_saved(dlco_ctx *c, float *W_host, int32_t *r, float *A_host)
     return guarded(c, [&] {
         DLCO_HIP(hipSetDevice(c->cfg.device));
         DLCO_CHECK(c->phase == 0, DLCO_ERR_INVALID, "dlco_get_saved: step in flight");
-        const size_t FF = (size_t)c->F * c->F;
         if (W_host) {
-            if (c->r_save_dev > 0) d2h(c, W_host, c->W_save_dev.p, (size_t)c->r_save_dev * c->F * sizeof(float));
-            else std::memset(W_host, 0, FF * sizeof(float));
+            if (c->r_save_dev > 0) d2h_rows(c, W_host, c->W_save_dev.p, (size_t)c->r_save_dev);
+            else std::memset(W_host, 0, (size_t)c->Fu * c->Fu * sizeof(float));
         }
         if (A_host) {
             build_A(c, c->W_save_dev.p, c->r_save_dev);              // A+ = W^T W (:472-478 builds the same matrix as Evec * Bmul)
-            d2h(c, A_host, c->grad.p, FF * sizeof(float));
+            d2h_square(c, A_host, c->grad.p);
         }
     });
 }

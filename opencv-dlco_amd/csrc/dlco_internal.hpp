@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,6 +35,21 @@ struct Error : std::runtime_error {
     do {                                                                           \
         if (!(cond)) throw ::dlco::Error((code), std::string(msg));                \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device, and contexts may
+// be created on several devices and from several threads (cfg.device)
+inline void ensure_dynamic_lds(const void *func, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    int dev = 0;
+    DLCO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == func && d.second == dev) return;
+    DLCO_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(func, dev);
+}
 
 // simple owning device buffer
 template <typename T>
@@ -241,7 +258,8 @@ void pack_cols(float *dst, const float *src, long ld, int c0, int cw, int rows, 
 void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int world, hipStream_t s);
 
 // synthetic stand-in for a *-unproj.h5 generated in HBM (bench): d = U^T z + eps, clipped
-void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
+// (rows of F values at row stride ld >= F; columns beyond F are left alone)
+void synth_rows(float *D, int N, int F, long ld, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
                 float noise, float jitter, hipStream_t s);
 
 // ---------------------------------------------------------------------------

@@ -13,10 +13,10 @@ namespace {
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 }  // namespace
 
-EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream)
-    : F_(F), guard_(guard), max_iter_(max_iter), tol_(tol), s_(stream)
+EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream, int live_cols)
+    : F_(F), live_(live_cols > 0 ? std::min(live_cols, F) : F), guard_(guard), max_iter_(max_iter), tol_(tol), s_(stream)
 {
-    cap_ = std::min(F, std::max(max_rows, 2 * guard + 32));
+    cap_ = std::min(live_, std::max(max_rows, 2 * guard + 32));
     if (guard_ > cap_ / 2) guard_ = std::max(1, cap_ / 2);
     for (int i = 0; i < 6; i++) { buf_[i].alloc((size_t)cap_ * F_); all_[i] = buf_[i].p; }
     Q_ = all_[0]; Y_ = all_[1];
@@ -34,7 +34,14 @@ EigTracker::EigTracker(int F, int max_rows, int guard, float tol, int max_iter, 
     dead_.alloc(CHOL_INV_MAX_N);
     if (const char *e = std::getenv("DLCO_PANEL_AMP")) panel_amp_ = std::max(1.0, std::atof(e));
     // filter products run on the bf16 matrix cores with split operands unless DLCO_FP32_FILTER is set
-    bf16_filter_ = (F_ % 512 == 0) && std::getenv("DLCO_FP32_FILTER") == nullptr;
+    bf16_filter_ = (F_ % 128 == 0) && std::getenv("DLCO_FP32_FILTER") == nullptr;
+    // K slices of a product over a full (unpacked) matrix: a divisor of the tile count, four where it divides
+    {
+        const int nt = F_ / 128;
+        ks_ = 1;
+        for (int d : {4, 2, 8, 7, 6, 5, 3})
+            if (nt > 0 && nt % d == 0) { ks_ = d; break; }
+    }
     if (bf16_filter_) {
         plane_hi_.alloc(bf16x2_plane_bytes(std::min(cap_, 160), F_));
         plane_lo_.alloc(bf16x2_plane_bytes(std::min(cap_, 160), F_));
@@ -99,8 +106,9 @@ void EigTracker::append_random(float *Q, int have, int add)
 {
     if (add <= 0) return;
     y_ok_ = false;
-    h_tmp_.resize((size_t)add * F_);
-    for (size_t i = 0; i < h_tmp_.size(); i++) h_tmp_[i] = next_uniform();
+    h_tmp_.assign((size_t)add * F_, 0.f);
+    for (int i = 0; i < add; i++)
+        for (int j = 0; j < live_; j++) h_tmp_[(size_t)i * F_ + j] = next_uniform();   // (zero in the pad columns)
     DLCO_HIP(hipMemcpyAsync(Q + (size_t)have * F_, h_tmp_.data(), h_tmp_.size() * sizeof(float), hipMemcpyHostToDevice, s_));
     DLCO_HIP(hipStreamSynchronize(s_));
 }
@@ -113,7 +121,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     // (one HBM-bound pass over G per chunk, still cheaper than the generic fp32 GEMM)
     // (the row-streaming kernel takes 160 rows with the two-way split - a block of rank ~128 plus its guards
     // in ONE pass over G - and 96 with the three-way split; a sharded rank's slab kernel 128)
-    const int one_pass = (approx && !shard_ && F_ % 512 == 0) ? 160 : (packed_ ? 96 : 128);   // (symmetric three-way kernel: 96 rows)
+    const int one_pass = (approx && !shard_ && bf16_filter_) ? 160 : (packed_ ? 96 : 128);   // (symmetric three-way kernel: 96 rows)
     if (rows > one_pass && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
         chain_next_ = false;                                     // row chunks share the plane buffers: no carried planes
         const int step = approx ? (rows <= 2 * one_pass ? (rows / 2 + 31) / 32 * 32 : one_pass) : 96;
@@ -148,7 +156,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         bool done = false;
         if (bf16_filter_ && rows <= 128 && (approx || plane_lo2_.p)) {
-            int ks = 4;                                              // keep ~256 workgroups in flight
+            int ks = ks_;                                            // keep ~256 workgroups in flight
             while (ks < 4 * world && F_ % (128 * ks * 2) == 0 && bf16x2_slab_floats(rows, cw, ks * 2) <= slab_floats_) ks *= 2;
             done = skinny_product_bf16x2(X, F_, rows, G + c0, F_, cw, F_, alpha, out + c0, F_, E1s, b1, E2s, b2, plane_hi_.p,
                                          plane_lo_.p, slab_.p, s_, ks, approx ? nullptr : plane_lo2_.p);
@@ -177,7 +185,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
         // filter products: two-way split (~1e-5); exact products (Rayleigh-Ritz): three-way split (~1e-7)
         if (prof_) prof_->begin(PROF_EIG_PRODUCT);
         const bool ok = skinny_product_bf16x2(X, F_, rows, G, F_, F_, F_, alpha, out, F_, E1, b1, E2, b2, plane_hi_.p,
-                                              plane_lo_.p, slab_.p, s_, 0, approx ? nullptr : plane_lo2_.p);
+                                              plane_lo_.p, slab_.p, s_, ks_, approx ? nullptr : plane_lo2_.p);
         if (prof_) prof_->end(PROF_EIG_PRODUCT);
         if (ok) return;
     }
@@ -334,8 +342,8 @@ void EigTracker::refresh_lower_bound(const float *G, int iters, float theta_top)
     static const float kZero = 0.f;
     const bool cold = !have_lo_;
     if (cold) {
-        std::vector<float> v(F_);
-        for (int i = 0; i < F_; i++) v[i] = next_uniform();
+        std::vector<float> v(F_, 0.f);
+        for (int i = 0; i < live_; i++) v[i] = next_uniform();
         DLCO_HIP(hipMemcpyAsync(pv_.p, v.data(), F_ * sizeof(float), hipMemcpyHostToDevice, s_));
         DLCO_HIP(hipStreamSynchronize(s_));
         row_normalize(pv_.p, F_, 1, F_, s_);
@@ -398,7 +406,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         panel_ends.clear();
         // The filter is only applied to a block of Ritz vectors (theta known): the amplification of
         // each row is then predictable and the panels of the orthonormalisation can follow it.
-        if (m_ < F_ && n_ritz > 0) {
+        if (m_ < live_ && n_ritz > 0) {
             // ---- Chebyshev filter of degree d damping [a, b] of H = -G ---------------------------
             const float a = lo_bound_;
             float b = std::min(block_min, mu);
@@ -553,7 +561,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             const bool small = cscale * h_res_[i] <= gtol;
             guards_ok = guards_ok && (below || small);
         }
-        if (m_ >= F_) conv = true;                                   // dense: Rayleigh-Ritz is exact
+        if (m_ >= live_) conv = true;                                // dense: Rayleigh-Ritz is exact
         else if (nw == 0) conv = guards_ok || it >= 6;
         else conv = crit <= tol * emax && guards_ok;
         if (debug_)
@@ -562,7 +570,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                          (int)guards_ok, (int)conv);
         if (h_theta_[m_ - 1] < lo_bound_) lo_bound_ = h_theta_[m_ - 1] - 0.5f * std::fabs(h_theta_[m_ - 1]) - 1e-12f;
         // ---- grow the block when the positive eigenspace reaches into the guard ------------------
-        if (m_ < F_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {
+        if (m_ < live_ && m_ < cap_ && nw > m_ - std::max(2, guard_ / 2)) {
             const int add = std::min(cap_ - m_, std::max(guard_, nw / 4));
             // half of the new rows from the caller's source (rows of the step's batch), the rest random: the directions
             // that have just risen above mu lie mostly in the span of recent batch rows, and a block that starts there
@@ -578,7 +586,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         // a full block that cannot grow while the positive eigenspace still reaches into its guards
         // cannot certify the rank: the reference keeps EVERY positive eigen-direction
         // (src/pj-learn.cpp:480-484), so this is reported, never silently truncated
-        if (m_ < F_ && m_ >= cap_ && nw > m_ - std::max(2, guard_ / 2)) { conv = false; it++; break; }
+        if (m_ < live_ && m_ >= cap_ && nw > m_ - std::max(2, guard_ / 2)) { conv = false; it++; break; }
         if (conv) { it++; break; }
     }
     st_.iters += it;

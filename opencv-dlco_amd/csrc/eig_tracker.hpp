@@ -25,7 +25,9 @@ struct EigStats {
 
 class EigTracker {
 public:
-    EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream);
+    // live_cols: the columns [live_cols, F) of every row of G are zero padding (dlco_api.cpp pads FeatDim to whole
+    // tiles): the block never leaves the span of the first live_cols coordinates, and its size is bounded by it
+    EigTracker(int F, int max_rows, int guard, float tol, int max_iter, hipStream_t stream, int live_cols = 0);
     ~EigTracker();
 
     // Forget the subspace (next update seeds from `seed_rows` or random vectors).
@@ -56,7 +58,7 @@ public:
     int readback_extra() const { return extra_val_; }
     void set_packed(bool on) { packed_ = on; }
     bool packed() const { return packed_; }
-    static bool packed_supported(int F) { return F == 8192 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }
+    static bool packed_supported(int F) { return F % 128 == 0 && F / 128 <= 64 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }
     const EigStats &stats() const { return st_; }
     float last_crit() const { return last_crit_; }
 
@@ -74,7 +76,7 @@ private:
     float next_uniform();
     float *pick(std::initializer_list<const float *> busy) const;
 
-    int F_, cap_, guard_, max_iter_;
+    int F_, live_, cap_, guard_, max_iter_;
     float tol_;
     std::function<int(float *, int)> grow_cb_;
     const int *extra_dev_ = nullptr;
@@ -114,6 +116,7 @@ private:
     int *sweeps_dev_ = nullptr;
     DevBuf<int32_t> srcrow_;
     bool bf16_filter_ = false;       // filter products as split-bf16 MFMA (kernels_bf16x2.hip)
+    int ks_ = 4;                     // K slices of such a product over a full matrix (a divisor of F / 128)
     DevBuf<char> plane_hi_, plane_lo_, plane_lo2_;
     DevBuf<int> dead_;               // dead-row flags of the panel being factored
     size_t slab_floats_ = 0;

@@ -447,8 +447,13 @@ __global__ __launch_bounds__(256) void reduce_split_kernel(const float *slab, in
 constexpr int SYM_TS = 132;                // LDS row stride of a transposed chunk image (floats)
 static_assert(RK_KC * SYM_TS * 4 <= RK_GBYTES, "a transposed chunk image must fit the G image");
 
+// Other widths (round 4): nt = K / 128 tile rows are embedded in Z_2^b, 2^b = the next power of two >= max(nt, 4); the same
+// pairing runs on 4 * 2^b workgroups, of which those of a block I >= nt leave at once and the others skip partners
+// J >= nt (a workgroup's list of real partners sits in LDS).  Below 64 tile rows there are fewer than 256 workgroups and
+// the XCD placement is whatever the dispatcher does: the matrix is then at most 34 MB and the pass is short anyway.
 struct SymDev {
     int M, K;
+    int nt, lb;                   // tile rows K / 128, log2 of the padded tile count (2..6)
     const bf16x8 *xhi, *xlo, *xlo2;
     const float *G;               // packed upper tiles: tile (I, J), I <= J, at (I*nt - I*(I-1)/2 + J - I) * 16384 floats
     float *slab;                  // [4][M][K] raw partial sums
@@ -462,23 +467,35 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
     constexpr int APLANE = MT * 256;
     constexpr int AENT = NS * APLANE;
     constexpr int NA = (AENT + 255) / 256;
-    constexpr int NT = 64;                                     // tile rows (K = 8192)
+    const int NT = g.nt, lb = g.lb;                            // tile rows; 2^lb = padded tile count
     float *gb0 = reinterpret_cast<float *>(lds_raw), *gb1 = reinterpret_cast<float *>(lds_raw + RK_GBYTES);
     bf16x8 *ab0 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES), *ab1 = reinterpret_cast<bf16x8 *>(lds_raw + 2 * RK_GBYTES + ABYTES);
+    __shared__ int jlist[16];                                  // the real partners of this workgroup, in schedule order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // workgroup -> (group p, half c, block I): see above
+    // workgroup -> (group p, half c, block I): see above (bits 5, 4 there are bits lb-1, lb-2 here)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int p = xcd >> 1, c = xcd & 1;
     int I;
-    if (p == 0 || p == 3) I = (c << 5) | slot;
+    if (p == 0 || p == 3) I = (c << (lb - 1)) | slot;
     else {
-        const int b5 = slot >> 4, b4 = p == 1 ? c : (b5 ^ c);
-        I = (b5 << 5) | (b4 << 4) | (slot & 15);
+        const int b5 = slot >> (lb - 2), b4 = p == 1 ? c : (b5 ^ c);
+        I = (b5 << (lb - 1)) | (b4 << (lb - 2)) | (slot & ((1 << (lb - 2)) - 1));
     }
-    const int dbase = (p == 0 ? 1 : (p == 1 ? 2 : (p == 2 ? 3 : 0))) << 4;
-    constexpr int nchunks = 32;                                // 16 tiles x 2 halves of 64 k
+    if (I >= NT) return;                                       // a block of the padding: the whole workgroup leaves
+    const int dbase = (p == 0 ? 1 : (p == 1 ? 2 : (p == 2 ? 3 : 0))) << (lb - 2);
+    int nchunks;                                               // real partner tiles x 2 halves of 64 k
+    {
+        const int nslots = 1 << (lb - 2);
+        int cnt = 0;
+        for (int sl = 0; sl < nslots; sl++) {
+            const int J = I ^ (dbase | sl);
+            if (J < NT) { if (tid == 0) jlist[cnt] = J; cnt++; }
+        }
+        nchunks = 2 * cnt;
+    }
+    __syncthreads();
     // chunk cc: partner block, orientation, byte offset of the stored tile
-    auto partner = [&](int cc) { return I ^ (dbase | (cc >> 1)); };
+    auto partner = [&](int cc) { return jlist[cc >> 1]; };
     auto tile_bytes = [&](int J) {
         const int a = min(I, J), b = max(I, J);
         return (a * NT - a * (a - 1) / 2 + (b - a)) * (128 * 128 * (int)sizeof(float));
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
         struct Stage { f32x4 gq[8]; bf16x8 aq[NA]; };
         Stage s0, s1;
         auto gload = [&](int cc, Stage &st) {
-            const int J = partner(cc), half = cc & 1;
+            const int J = __builtin_amdgcn_readfirstlane(partner(cc)), half = cc & 1;
             const bool direct = I <= J;
             const int voff = direct ? voff_d : voff_t;
             const int soff = tile_bytes(J) + (direct ? half * 64 : half * 64 * 128) * (int)sizeof(float);
@@ -526,21 +543,26 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
         };
         // chunk q: multiplied in iteration q, copied to image q & 1 at the start of iteration q - 1, requested at iteration
         // q - 3 into register set q & 1 (chunks 0..2 before the loop); no branch around a load in the steady state
-        gload(0, s0);
-        gload(1, s1);
-        gstore(0, s0);
-        gload(2, s0);
+        // (nchunks is even; a workgroup without a real partner - nchunks = 0 - only joins the barriers)
+        if (nchunks > 0) {
+            gload(0, s0);
+            gload(1, s1);
+            gstore(0, s0);
+            if (nchunks > 2) gload(2, s0);
+        }
         __syncthreads();
         int cc = 0;
         for (; cc + 4 < nchunks; cc += 2) {
             gstore(cc + 1, s1); gload(cc + 3, s1); __syncthreads();
             gstore(cc + 2, s0); gload(cc + 4, s0); __syncthreads();
         }
-        // cc = 28: chunks 29, 30 wait in s1, s0; chunk 31 is still to be requested
-        gstore(29, s1); gload(31, s1); __syncthreads();            // iteration 28
-        gstore(30, s0); __syncthreads();                           // iteration 29
-        gstore(31, s1); __syncthreads();                           // iteration 30
-        __syncthreads();                                           // iteration 31
+        // tail: iterations cc .. nchunks - 1 (cc = nchunks - 4 when nchunks >= 4, else 0), the same sequence with guards
+        for (; cc < nchunks; cc++) {
+            Stage &set = ((cc + 1) & 1) ? s1 : s0;
+            if (cc + 1 < nchunks) gstore(cc + 1, set);
+            if (cc + 3 < nchunks) gload(cc + 3, set);
+            __syncthreads();
+        }
         __syncthreads();                                           // the compute waves' K-half exchange
         return;
     }
@@ -636,25 +658,15 @@ template <int MT, int NS>
 void launch_sym(const SymDev &g, hipStream_t s)
 {
     const size_t lds = rk_lds_bytes(MT, NS);
-    static bool attr = false;
-    if (!attr) {
-        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL((skinny_sym_kernel<MT, NS>), dim3(256), dim3(RK_T), lds, s, g);
+    ensure_dynamic_lds(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS>), (int)lds);
+    hipLaunchKernelGGL((skinny_sym_kernel<MT, NS>), dim3(4u << g.lb), dim3(RK_T), lds, s, g);
 }
 
 template <int MT, int NS>
 void launch_rows(const Bf2Dev &g, dim3 grid, hipStream_t s)
 {
     const size_t lds = rk_lds_bytes(MT, NS);
-    static bool attr = false;
-    if (!attr) {
-        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_rows_kernel<MT, NS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void *>(skinny_rows_kernel<MT, NS>), (int)lds);
     hipLaunchKernelGGL((skinny_rows_kernel<MT, NS>), grid, dim3(RK_T), lds, s, g);
 }
 
@@ -737,7 +749,8 @@ bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, i
                         hipStream_t s, void *plane_lo2, bool planes_ready, bool emit_planes)
 {
     const int mt = (M + 31) / 32;
-    if (F != 8192 || M < 1 || mt > 5 || (mt >= 4 && plane_lo2)) return false;
+    const int nt = F / 128;
+    if (F % 128 != 0 || nt < 1 || nt > 64 || M < 1 || mt > 5 || (mt >= 4 && plane_lo2)) return false;
     if (ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || (reinterpret_cast<uintptr_t>(Gpacked) & 15) != 0) return false;
     if ((planes_ready || emit_planes) && plane_lo2) return false;       // the carried planes are the two-way ones
     const long total = (long)(F / 16) * mt * 64;
@@ -746,6 +759,8 @@ bool skinny_product_sym(const float *X, long ldx, int M, const float *Gpacked, i
                            static_cast<bf16x8 *>(plane_hi), static_cast<bf16x8 *>(plane_lo), static_cast<bf16x8 *>(plane_lo2));
     SymDev g;
     g.M = M; g.K = F;
+    g.nt = nt; g.lb = 2;
+    while ((1 << g.lb) < nt) g.lb++;
     g.xhi = static_cast<const bf16x8 *>(plane_hi); g.xlo = static_cast<const bf16x8 *>(plane_lo); g.xlo2 = static_cast<const bf16x8 *>(plane_lo2);
     g.G = Gpacked; g.slab = slab;
     if (plane_lo2) {

@@ -425,12 +425,7 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
 template <int NBM>
 static void launch_chol_inv2(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_inv2_kernel<NBM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(c2_lds_floats(NBM) * sizeof(float))));
-        attr = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void *>(chol_inv2_kernel<NBM>), (int)(c2_lds_floats(NBM) * sizeof(float)));
     hipLaunchKernelGGL(chol_inv2_kernel<NBM>, dim3(1), dim3(C2_T), c2_lds_floats(NBM) * sizeof(float), s, M, ldm, n, rel_thresh, Linv, ldl, dead);
 }
 

@@ -502,12 +502,7 @@ template <int E>
 void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, long ldv, int *sweeps_out, float stop_cos, float lam_cut,
                        hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
-        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_blk_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - 1024));
-        attr = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_blk_kernel<E>), 160 * 1024 - 1024);
     hipLaunchKernelGGL(jacobi_blk_kernel<E>, dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv,
                        sweeps_out, stop_cos, lam_cut);
 }
@@ -765,11 +760,7 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         DLCO_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
         g.sync = sync_words; g.sweeps_out = sweeps_out; g.stop_cos = stop_cos; g.lam_cut = lam_cut;
         const size_t lds = ((size_t)16 * g.ldc + 128) * sizeof(float);
-        static bool attr_mw = false;
-        if (!attr_mw) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_mw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-            attr_mw = true;
-        }
+        ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_mw_kernel), 160 * 1024 - 1024);
         hipLaunchKernelGGL(jacobi_mw_kernel, dim3(g.nbe / 2), dim3(JMW_T), lds, s, g);
     } else {
         hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, col_stride(n), evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);

@@ -272,12 +272,7 @@ template <int MT, int NS, bool PAIR, bool SLAB>
 void launch_project(const ProjDev &g, dim3 grid, hipStream_t s)
 {
     const size_t lds = pk_lds_bytes(MT, NS);
-    static bool attr = false;
-    if (!attr) {
-        DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<MT, NS, PAIR, SLAB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void *>(project_rows_kernel<MT, NS, PAIR, SLAB>), (int)lds);
     hipLaunchKernelGGL((project_rows_kernel<MT, NS, PAIR, SLAB>), grid, dim3(PK_T), lds, s, g);
 }
 

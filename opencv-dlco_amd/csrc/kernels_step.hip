@@ -299,7 +299,7 @@ __device__ __forceinline__ float gauss(uint64_t key)
 // row i: label 1 when i is even; d = U^T z + noise*eps, z ~ N(0, (sigma*s_i)^2 I_k), clipped to [-1, 1].
 // s_i = exp(jitter * g_i) is a per-row log-normal scale: it makes the two classes overlap the way real
 // match / non-match distances do (FPR@95 of a few per cent instead of perfectly separable rows).
-__global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, const float *U, int k, uint64_t seed,
+__global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, long ld, const float *U, int k, uint64_t seed,
                                                     float sig_pos, float sig_neg, float noise, float jitter)
 {
     extern __shared__ float z[];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, cons
         for (int q = 0; q < k; q++) v += z[q] * U[(long)q * F + f];
         v += noise * gauss(seed * 0x100000001B3ULL + ((uint64_t)i << 20) + (uint64_t)f);
         v = fminf(1.0f, fmaxf(-1.0f, v));
-        D[(long)i * F + f] = v;
+        D[(long)i * ld + f] = v;
     }
 }
 
@@ -433,10 +433,10 @@ void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const
     DLCO_HIP(hipGetLastError());
 }
 
-void synth_rows(float *D, int N, int F, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
+void synth_rows(float *D, int N, int F, long ld, const float *U, int k, uint64_t seed, float sig_pos, float sig_neg,
                 float noise, float jitter, hipStream_t s)
 {
-    hipLaunchKernelGGL(synth_kernel, dim3(N), dim3(256), k * sizeof(float), s, D, N, F, U, k, seed, sig_pos, sig_neg,
+    hipLaunchKernelGGL(synth_kernel, dim3(N), dim3(256), k * sizeof(float), s, D, N, F, ld, U, k, seed, sig_pos, sig_neg,
                        noise, jitter);
     DLCO_HIP(hipGetLastError());
 }

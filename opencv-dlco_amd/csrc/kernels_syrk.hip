@@ -695,16 +695,12 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         // workgroups sharing a CU reach 72 % of the matrix rate, the 5 us of a tile's 23 outside the loop - first
         // pieces, old tile, stores - and the last of its 4.06 rounds.)
         constexpr int NST = 3;
-        static bool attr = false;
-        if (!attr) {
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            DLCO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * PL_STAGE));
-            attr = true;
-        }
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST>), NST * PL_STAGE);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST>), NST * PL_STAGE);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST>), NST * PL_STAGE);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<false, false, NST, true>), NST * PL_STAGE);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<true, false, NST, true>), NST * PL_STAGE);
+        ensure_dynamic_lds(reinterpret_cast<const void *>(syrk_planes_kernel<false, true, NST, true>), NST * PL_STAGE);
         if (prec == 1) {
             if (packed) hipLaunchKernelGGL((syrk_planes_kernel<false, true, NST, true>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);
             else if (slab) hipLaunchKernelGGL((syrk_planes_kernel<true, false, NST, true>), dim3(ntiles), dim3(NTP), NST * PL_STAGE, s, g, planes);

@@ -32,9 +32,10 @@ class HipEngine:
 
     def __init__(self, dlco, ctx, device):
         self.dlco, self.ctx = dlco, ctx
-        B, F = ctx.B, ctx.F
+        B = ctx.B
+        _, grad_bytes = ctx.dev_buffer(dlco.BUF_GRAD)       # (device width)^2 floats: F padded to whole tiles
         self.dist = torch.zeros(2 * B, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(F * F, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(grad_bytes // 4, dtype=torch.float32, device=device)
         torch.cuda.synchronize(device)
         ctx.bind_buffer(dlco.BUF_DIST, self.dist.data_ptr(), self.dist.numel() * 4)
         ctx.bind_buffer(dlco.BUF_GRAD, self.grad.data_ptr(), self.grad.numel() * 4)

@@ -48,7 +48,7 @@ def test_no_cpu_fallback_without_gpu(dlco):
 
 def test_invalid_configs_are_rejected_before_touching_the_device(dlco):
     lib = dlco.load()
-    for F, N, B, world, rank in ((30, 100, 4, 1, 0), (32, 1, 4, 1, 0), (32, 100, 0, 1, 0), (32, 100, 5, 2, 0), (32, 100, 4, 2, 2)):
+    for F, N, B, world, rank in ((0, 100, 4, 1, 0), (-8, 100, 4, 1, 0), (32, 1, 4, 1, 0), (32, 100, 0, 1, 0), (32, 100, 5, 2, 0), (32, 100, 4, 2, 2)):
         cfg = dlco.Cfg()
         lib.dlco_cfg_default(C.byref(cfg))
         cfg.F, cfg.N, cfg.B, cfg.world, cfg.rank = F, N, B, world, rank
