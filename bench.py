@@ -62,6 +62,18 @@ WORKLOADS = {
                # step 640 (DLCO_EIG_DEBUG trace, profiles/r2_c3_rank_trajectory.txt): the named regime, rank ~128, is reached
                # after ~500 steps, and before that every step still takes 2-3 tracker passes on a block of 192+ rows
                rank_band=(100, 160), fpr95_band=(0.02, 0.15), burn_in=500),
+    # The shape the reference itself ran (every committed log: 500000 x 480 or x 544, batch 200 + 200; this one is
+    # workspace/pj-learn/logging/liberty-liberty-0.035-0.250-pr#7-0.0010-0.100-pj.log: mu 0.001, gamma 0.1, rank 71 at
+    # step 500 and 67 at the end, FPR95 9.19 % -> 5.67 %).  544 is not a multiple of the kernels' 128-column tile: the
+    # library keeps the rows at 640 floats (include/dlco.h, dlco_device_width).  The CPU port runs FULL steps here
+    # (ssyevr at n = 544 is ~0.1 s), and the reference's own logs give its Ttime.
+    "ref544": dict(name="reference-real shape (liberty 544-wide run)", F=544, N=500000, batch=200, mu=0.001, gamma=0.1,
+                   latent=96, sigma_pos=0.35, sigma_neg=1.0, noise=0.05, jitter=0.3, seed=2216,
+                   rank_band=(40, 100), fpr95_band=(0.02, 0.15), burn_in=300, cpu_steps=50, cpu_rows=20000,
+                   reference_logged={"Ttime_s_per_100_steps": {"mean": 7.46, "p05": 6.35, "p95": 8.62}, "ms_per_step": 74.6,
+                                     "pair_rows_per_s": 5.4e3, "hardware": "unknown x86 host (OpenBLAS + OpenMP), GTX 970 for validation only",
+                                     "source": "BASELINE.md section 1: Ttime of the 135 reference logs with `Load Distances: 500000 x 544`",
+                                     "note": "context only: another machine, the real Liberty data"}),
 }
 
 
@@ -124,15 +136,29 @@ def committed_profile(name):
         return None
 
 
+CURRENT_ROUND = 4
+
+
+def committed_pmc(stem):
+    """A committed rocprofv3 --pmc summary (profiles/rN_<stem>.json), newest round first, with where it came from: PMC
+    counters cannot be read inside a timed run, so these figures are NOT measured by this invocation; a file of an earlier
+    round than the code is marked stale."""
+    for rnd in range(CURRENT_ROUND, 0, -1):
+        name = "r%d_%s.json" % (rnd, stem)
+        d = committed_profile(name)
+        if d:
+            return d, {"file": "profiles/" + name, "round": rnd, "stale": rnd != CURRENT_ROUND,
+                       "measured_in_this_run": False}
+    return None, None
+
+
 def pmc_traffic(F, bl):
     """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this command, gfx950 read correction applied).  PMC counters cannot be read
-    inside a timed run, so the figure is the committed one; it is only reported for the
+    WRITE_SIZE runs of this command, gfx950 read correction applied); only reported for the
     configuration it was measured on."""
-    for name in ("r3_pmc_syrk.json", "r2_pmc_syrk.json", "r1_pmc_syrk.json"):
-        d = committed_profile(name)
-        if d and F == 8192 and bl == 200:
-            return d.get("hbm_bytes_per_launch_corrected"), name
+    d, src = committed_pmc("pmc_syrk")
+    if d and F == 8192 and bl == 200:
+        return d.get("hbm_bytes_per_launch_corrected"), src
     return None, None
 
 
@@ -262,6 +288,90 @@ def reference_run(dlco, wl, data_ctx, iters, logstep, kw):
                     "`value` times steady-state steps only, like the reference's Ttime per 100 steps divided out)"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher.  It
+    has not imported torch.cuda, the product library or anything else that touches HIP (and never will): it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a CHILD process (no exec of a process
+    that has initialised the GPU - nothing here has), passes rank 0's single JSON line through to its own stdout and
+    exits with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DLCO_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    out, _ = p.communicate()
+    lines = [l for l in out.splitlines() if l.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def dry_launch(args):
+    """`--dry-launch`: the launcher path without a GPU - every rank joins a gloo process group, the step is the CPU oracle's
+    (test infrastructure, a tiny problem), the barrier / max-over-ranks timing and the one JSON line are the real
+    code's.  What tests/test_bench_launcher.py runs in the container."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import synth
+    D, L = synth(600, 32, k=6, seed=5)
+    tr = ref.Trainer(D, L, B=8, mu=0.004, gamma=0.5, grad_order=1)
+    for _ in range(args.warmup):
+        tr.step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ranks = torch.tensor([1], dtype=torch.int64)
+    dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "pj-learn patch-pairs/sec", "dry_launch": True, "value": 2.0 * 8 * args.steps * world / float(tmax.item()),
+                          "unit": "pair-rows/s", "n_gpus": world, "ranks_joined": int(ranks.item()), "steps": args.steps, "warmup": args.warmup,
+                          "data": "synthetic (CPU oracle, launcher rehearsal: not a measurement)"}), flush=True)
+    tr.close()
+    dist.destroy_process_group()
+    return 0
+
+
+def side_run(dlco, wl, kw, steps, warmup, data_from=None):
+    """A short timed run of another BASELINE configuration in the same invocation (so that the driver's record carries a
+    number for it): burn-in to the named rank regime, warm-up, `steps` timed full steps, then where the trainer stands."""
+    c = build_context(dlco, wl, data_from=data_from, **kw)
+    c.steps(wl.get("burn_in", 300))
+    c.steps(warmup)
+    c.sync()
+    t0 = time.perf_counter()
+    c.steps(steps)
+    c.sync()
+    dt = time.perf_counter() - t0
+    e = c.log_step()
+    cn = c.counters()
+    r = {"workload": wl["name"], "value": 2.0 * wl["batch"] * steps / dt, "unit": "pair-rows/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+         "warmup": warmup, "burn_in_steps": wl.get("burn_in", 300), "rank": int(e.rank), "fpr95": e.fpr95, "auc": e.auc,
+         "nonconverged_steps": cn["nonconverged"], "dtype": "bf16 MFMA inputs + fp32 accumulate in every GEMM over the resident matrix"
+         if kw.get("grad_bf16") else "f32"}
+    c.close()
+    return r
+
+
 class Runner:
     """One trainer (context + optional distributed wrapper) and its timed run."""
 
@@ -305,7 +415,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2",
-                    help="c2 = BASELINE configs[1] (rank ~64, the metric's configuration); c3 = configs[2] (rank ~128)")
+                    help="c2 = BASELINE configs[1] (rank ~64, the metric's configuration); c3 = configs[2] (rank ~128); "
+                         "ref544 = the shape the reference itself ran (500000 x 544, mu 0.001, gamma 0.1)")
     ap.add_argument("--burn-in", type=int, default=None,
                     help="full training steps run while the workload is set up, to reach the rank regime the "
                          "BASELINE configuration names (default: 300 for c2, 500 for c3; 0 = time the start-up transient)")
@@ -317,8 +428,8 @@ def main():
     ap.add_argument("--latent", type=int, default=None)
     ap.add_argument("--jitter", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=4096)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the CPU baseline's subset (default 4096; 20000 for ref544)")
+    ap.add_argument("--cpu-steps", type=int, default=None, help="full steps of the CPU baseline (default 3; 50 for ref544)")
     ap.add_argument("--cpu-t0", action="store_true", help="also time the worst-case first iteration (W = 0) on the CPU")
     ap.add_argument("--pair-mode", action="store_true",
                     help="train from per-patch descriptors + the Indices table (dlco_set_pairs), differences formed "
@@ -344,16 +455,24 @@ def main():
                     help="developer check: no HIP events inside the timed region (the roofline / breakdown fields are then empty)")
     ap.add_argument("--guard", type=int, default=None, help="tracker guard vectors (library default 32)")
     ap.add_argument("--eig-tol", type=float, default=None, help="tracker tolerance (library default 2e-4)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the N-rank launch on the CPU (gloo + the oracle's step on a toy problem): no GPU is touched")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="single GPU, default workload: skip the short configs[2] and configs[4] runs reported as other_configs")
     args = ap.parse_args()
 
+    # N > 1 without a launcher around us: become the launcher BEFORE anything touches the GPU (see self_launch)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.dry_launch:
+        sys.exit(dry_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N > 1" % (args.gpus, world), file=sys.stderr)
-        if args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     dlco = importlib.import_module("opencv-dlco_amd")
     wl = dict(WORKLOADS[args.config])
@@ -364,6 +483,10 @@ def main():
     F, N, Bl = wl["F"], wl["N"], wl["batch"]
     if args.burn_in is None:
         args.burn_in = wl.get("burn_in", 300)
+    if args.cpu_steps is None:
+        args.cpu_steps = wl.get("cpu_steps", 3)
+    if args.cpu_rows is None:
+        args.cpu_rows = wl.get("cpu_rows", 4096)
 
     use_dist = world > 1 or args.force_dist
     if args.force_dist:
@@ -457,16 +580,26 @@ def main():
         flops_launch /= world
     t_syrk = ms_syrk / max(n_syrk, 1) * 1e-3
     ach = flops_launch / t_syrk / 1e12 if n_syrk else None
-    peak_mfma = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS        # dense bf16 MFMA peak (same guide) for the --bf16 variant
     exec_flops = flops_launch if shard else flops_launch * (F // 128 + 1) / (2.0 * (F // 128))
     ach_exec = exec_flops / t_syrk / 1e12 if n_syrk else None
     traffic, traffic_src = pmc_traffic(F, Bl) if world == 1 and not args.pair_mode else (None, None)
-    sq = committed_profile("r3_pmc_sq.json") or committed_profile("r2_pmc_sq.json") or committed_profile("r1_pmc_sq.json")
+    sq, sq_src = committed_pmc("pmc_sq")
     mfma_busy = None
     try:
-        mfma_busy = sq["kernels"]["syrk_planes_kernel"]["mfma_util"]   # committed --pmc pass of this command (tools/collect_sq.sh)
+        if F == 8192:
+            mfma_busy = sq["kernels"]["syrk_planes_kernel"]["mfma_util"]   # committed --pmc pass of this command (tools/collect_sq.sh)
     except Exception:
         pass
+    # what the matrix pipe in use is asked to do: the fp32 result comes from bf16 MFMAs on three-way split operands, six per
+    # product term (one per term with --bf16: operands rounded once)
+    Fd = ctx.device_width()
+    ntile = Fd // 128
+    packed = world == 1 and not shard and ntile <= 64
+    issued_mult = 1.0 if args.bf16 else 6.0
+    exec_flops_dev = (flops_launch if shard else 2.0 * k_mean * Fd * Fd * (ntile + 1) / (2.0 * ntile))   # on the padded width the kernels run at
+    issued = issued_mult * exec_flops_dev
+    ach_issued = issued / t_syrk / 1e12 if n_syrk else None
+    dfavg_bytes = (ntile * (ntile + 1) // 2) * 65536.0 if packed else 4.0 * Fd * Fd / (world if shard else 1)
     # per pair-row 2F^2 + 2Fr flops (projection + gradient, dense)
     flops_pair_row = 2.0 * F * F + 2.0 * F * rank_now
     t_kernel_path = (ms_syrk / max(args.steps, 1) + ms_prj / bdiv) * 1e-3          # P1+P2 + Q1+U1 per step, HIP events
@@ -503,31 +636,35 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
+            "pipe": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16), operands rounded to bf16 once, fp32 accumulation" if args.bf16 else
+                     "bf16 MFMA (v_mfma_f32_32x32x16_bf16) producing fp32 results: operands split three ways, six bf16 MFMAs per fp32 product term"),
             "kernel": "grad_syrk_rda (fused weighted SYRK + dual average: syrk_split_rows_kernel + syrk_planes_kernel, both inside the timed launch)",
-            "achieved": ach_exec,
-            "peak": peak_mfma,
+            "achieved": ach_issued,
+            "peak": 2500.0,
             "unit": "TFLOP/s",
-            "frac": (ach_exec / peak_mfma) if ach_exec else None,
-            "note": "achieved = fp32 flops of the result the launch EXECUTES (the tiles on or above the diagonal, K = rows with a non-zero "
-                    "violation count) / the launch's HIP-event time, against the fp32 MFMA peak the contract names for dtype f32.  The fp32 "
-                    "results come from the bf16 matrix cores (operands split three ways, six bf16 MFMAs per fp32 product term), so the figure "
-                    "can pass 1.0: bf16_mfma_frac prices the same launch as the bf16 MFMA work it issues (6 x executed flops) against the "
-                    "2500 TFLOP/s bf16 peak, and mfma_busy_frac_pmc is the matrix pipe's busy share from the committed PMC pass.  "
-                    "algorithmic_* is SURVEY 8(d)'s dense accounting (2*K*F^2 per launch, no symmetry credit) over the same time; it exceeds "
-                    "the executed figure by ~2x because the kernel never computes the lower triangle, and is NOT a utilisation",
-            "bf16_mfma_frac": (None if args.bf16 or not ach_exec else 6.0 * ach_exec / 2500.0),
+            "frac": (ach_issued / 2500.0) if ach_issued else None,
+            "note": "frac is a utilisation of the pipe in use: MFMA flops ISSUED by the launch (%g x the fp32 flops of the tiles it computes - "
+                    "those on or above the diagonal, at the device width %d, K = rows with a non-zero violation count) / the launch's HIP-event "
+                    "time / the dense bf16 MFMA peak.  fp32_equivalent_* prices the executed fp32 flops against the fp32 MFMA peak the contract "
+                    "names for dtype f32 (it can pass 1.0 because the work runs on the faster pipe: NOT a utilisation); algorithmic_* is SURVEY "
+                    "8(d)'s dense accounting (2*K*F^2, no symmetry credit, caller's width) over the same time, also not a utilisation.  "
+                    "mfma_busy_frac_pmc and traffic come from committed PMC passes (see their *_source)" % (issued_mult, Fd),
+            "issued_mfma_flops_per_launch": issued,
+            "fp32_equivalent_achieved": ach_exec,
+            "fp32_equivalent_frac": (ach_exec / PEAK_F32_MFMA_TFLOPS) if ach_exec else None,
             "algorithmic_achieved": ach,
-            "algorithmic_frac": (ach / peak_mfma) if ach else None,
+            "algorithmic_frac": (ach / PEAK_F32_MFMA_TFLOPS) if ach else None,
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s); algorithmic bytes 8*F*F + 4*K*F = %d"
-                            % (traffic_src, int(8 * F * F + 4 * k_mean * F)),
+            "traffic_source": traffic_src,
+            "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE); algorithmic bytes 8*F*F + 4*K*F = %d; the packed layout needs %d"
+                            % (int(8 * F * F + 4 * k_mean * F), int(2 * dfavg_bytes + 12 * k_mean * Fd)),
             "avg_launch_ms": t_syrk * 1e3,
             "launches": n_syrk,
             "algorithmic_flops_per_launch": flops_launch,
             "mean_active_rows_per_launch": k_mean,
             "executed_flops_per_launch": exec_flops,
-            "executed_frac": (ach_exec / peak_mfma) if ach_exec else None,      # = frac (kept for readers of the round-2 lines)
             "mfma_busy_frac_pmc": mfma_busy,
+            "mfma_busy_source": sq_src if mfma_busy is not None else None,
             # kernel path only (P1+P2+V1+Q1+U1), (ii) end to end incl. the PSD projection
             "flops_per_pair_row": flops_pair_row,
             "kernel_path_frac": (2.0 * B / world * flops_pair_row / t_kernel_path / 1e12 / PEAK_F32_MFMA_TFLOPS) if t_kernel_path > 0 else None,
@@ -536,11 +673,29 @@ def main():
                 "kernel": "one pass of the eigen tracker over dfAvg (split-bf16 MFMA), HBM-bound",
                 "avg_launch_ms": t_prod * 1e3 if n_prod else None,
                 "launches_per_step": n_prod / bdiv,
-                "algorithmic_bytes_per_launch": 4.0 * F * F / (world if shard else 1),
-                "hbm_frac": (4.0 * F * F / (world if shard else 1) / t_prod / 1e12 / PEAK_HBM_TBS) if n_prod else None,
+                "necessary_bytes_per_launch": dfavg_bytes,
+                "layout": "packed upper 128 x 128 tiles, each fetched once per pass" if packed else "full matrix (column slab of a sharded rank)",
+                "hbm_frac": (dfavg_bytes / t_prod / 1e12 / PEAK_HBM_TBS) if n_prod else None,
             },
             "tracker_nonconverged_steps": cn1["nonconverged"] - cn0["nonconverged"],
         },
+        # one entry per kernel group of breakdown_ms_per_step, each priced on what it has to do: issued MFMA flops or the
+        # bytes the pass cannot avoid, its time per step, the fraction of that unit's peak
+        "step_roofline": [
+            {"group": "grad_syrk", "bound": "mfma (bf16 pipe)", "ms_per_step": ms_syrk / args.steps, "launches_per_step": n_syrk / max(args.steps, 1),
+             "work_per_launch": issued, "work_unit": "bf16 MFMA flops issued", "achieved": ach_issued, "peak": 2500.0, "unit": "TFLOP/s",
+             "frac": (ach_issued / 2500.0) if ach_issued else None},
+            {"group": "eig_products", "bound": "hbm", "ms_per_step": ms_prod / bdiv, "launches_per_step": n_prod / bdiv,
+             "work_per_launch": dfavg_bytes, "work_unit": "bytes of the dual average one pass must read",
+             "achieved": (dfavg_bytes / t_prod / 1e9) if n_prod else None, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+             "frac": (dfavg_bytes / t_prod / 1e12 / PEAK_HBM_TBS) if n_prod else None},
+            {"group": "eig_jacobi", "bound": "latency (m x m problem on one workgroup; a chain of dependent rotation rounds)",
+             "ms_per_step": ms_jac / bdiv, "launches_per_step": n_jac / bdiv, "frac": None},
+            {"group": "project", "bound": "latency (2B gathered rows x F x 4 bytes = %d per step)" % int(8 * B * Fd / world),
+             "ms_per_step": ms_prj / bdiv, "launches_per_step": n_prj / bdiv, "frac": None},
+            {"group": "other", "bound": "orthonormalisation (Gram, L^-1, L^-1 Z), rotation GEMMs, reductions, violation counts, launch gaps",
+             "ms_per_step": dt / args.steps * 1e3 - ms_syrk / args.steps - (ms_prod + ms_jac + ms_prj) / bdiv, "frac": None},
+        ],
         "breakdown_ms_per_step": {
             "grad_syrk": ms_syrk / args.steps,
             "eig_products": ms_prod / bdiv,
@@ -573,6 +728,18 @@ def main():
         out["other_modes"] = others
     if world == 1 and not args.pair_mode and args.reference_iters > 0:
         out["reference_run"] = reference_run(dlco, wl, ctx, args.reference_iters, args.reference_logstep, kw)
+    if wl.get("reference_logged"):
+        out["reference_logged"] = wl["reference_logged"]
+    # the other single-GPU configurations BASELINE names, timed by the same invocation: configs[2] (rank ~128) and the
+    # configs[4] variant (bf16 MFMA + fp32 accumulate) on the headline workload
+    if (world == 1 and args.config == "c2" and not args.pair_mode and not args.bf16 and not args.no_other_configs
+            and all(v is None for v in (args.F, args.N, args.batch, args.mu, args.gamma, args.latent, args.jitter))):
+        n_side = max(20, min(args.steps, 100))
+        kw_bf = dict(kw, grad_bf16=1)
+        out["other_configs"] = {
+            "configs[4] bf16 variant on configs[1]": side_run(dlco, wl, kw_bf, n_side, args.warmup, data_from=ctx),
+            "configs[2]": side_run(dlco, dict(WORKLOADS["c3"]), kw, n_side, args.warmup),
+        }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.pair_mode:
             out["cpu_baseline"] = cpu_baseline(ctx, wl, args.cpu_rows, args.cpu_steps, args.cpu_t0)

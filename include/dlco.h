@@ -292,7 +292,9 @@ int dlco_profile_enable(dlco_ctx *ctx, int32_t on);
 int dlco_profile_read(dlco_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
 /* Counters since creation: out[0] = training steps run, out[1] = sum over those steps of the
  * rows that entered this rank's gradient SYRK (rows with a non-zero violation count),
- * out[2] = steps whose eigen tracker stopped at its iteration cap, out[3..7] reserved. */
+ * out[2] = steps whose eigen tracker stopped at its iteration cap, out[3] = calls of the multi-workgroup
+ * Jacobi kernel that gave up at its bounded grid barrier (the m x m problem was then solved again on one
+ * workgroup: a slow event, never a wrong result), out[4..7] reserved. */
 int dlco_counters(const dlco_ctx *ctx, int64_t out[8]);
 /* Tracker statistics since creation: filter/RR iterations, H-products (in rows), restarts. */
 int dlco_eig_stats(const dlco_ctx *ctx, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps,

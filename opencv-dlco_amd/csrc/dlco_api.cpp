@@ -1316,6 +1316,7 @@ int dlco_counters(const dlco_ctx *c, int64_t out[8])
     if (!c || !out) return DLCO_ERR_INVALID;
     for (int i = 0; i < 8; i++) out[i] = 0;
     out[0] = c->steps_run; out[1] = c->active_rows_sum; out[2] = c->nonconv_steps;
+    out[3] = c->eig->stats().jacobi_barrier_timeouts;
     return DLCO_OK;
 }
 

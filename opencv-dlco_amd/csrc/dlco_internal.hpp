@@ -271,8 +271,10 @@ void synth_rows(float *D, int N, int F, long ld, const float *U, int k, uint64_t
 // lam_cut: a pair of columns whose eigenvalue estimates are BOTH below it is still rotated but does not
 // keep the sweeps going (the tracker's guard vectors: only their span matters, and the caller checks the
 // residuals of the pairs it keeps); the default counts every pair.
+// *sweeps_out < 0: the multi-workgroup kernel (160 < n <= 2048) gave up at its bounded grid barrier (its workgroups were
+// not all resident at once); evals / V are then NOT written and the caller repeats the call with single_workgroup = true.
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                 hipStream_t s, float lam_cut = -3.0e38f);
+                 hipStream_t s, float lam_cut = -3.0e38f, bool single_workgroup = false);
 size_t jacobi_work_floats(int n);
 // CholQR building block for panels of <= 160 rows: factors the panel's Gram matrix M = L L^T
 // (only its lower triangle is read) and returns Linv = L^-1 [n][ldl] (lower triangular, upper

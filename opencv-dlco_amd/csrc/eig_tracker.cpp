@@ -482,14 +482,17 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             const int ig = nwp + std::max(2, guard_ / 4);
             if (ig < m_) lam_cut = h_theta_[ig];
         }
-        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_, lam_cut);
-        if (prof_) prof_->end(PROF_JACOBI);
         float *Qn = pick({Qo, Yb});
         float *Yn = pick({Qo, Yb, Qn});
+        const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
+        // (second attempt: only after the multi-workgroup Jacobi gave up at its grid barrier - T, Qo and Yb are untouched
+        // by a failed attempt, the m x m problem is then solved again by the single-workgroup kernel)
+        for (int attempt = 0;; attempt++) {
+        jacobi_eigh(Tm_.p, cap_, m_, evals_.p, Vm_.p, cap_, jwork_.p, sweeps_dev_, s_, lam_cut, attempt > 0);
+        if (prof_) prof_->end(PROF_JACOBI);
         rotate(Vm_.p, cap_, m_, m_, Qo, Qn, Yb, Yn);
         Q_ = Qn; Y_ = Yn;
         y_ok_ = true;                                                // Y_ = Q_ H for the current H
-        const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
         if (!poll_readback_) residual_norms(Q_, Y_, F_, evals_.p, m_, F_, res_.p, s_);
         if (poll_readback_) {
             // the block is written into pinned memory by a kernel that raises a sequence number last; polling it
@@ -516,9 +519,15 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             DLCO_HIP(hipStreamSynchronize(s_));
         }
         if (extra_dev_) extra_val_ = *reinterpret_cast<int *>(pin_ + pin_floats_ - 32);
+        const int sweeps = *reinterpret_cast<int *>(pin_ + 2 * (cap_ + 8));
+        if (sweeps >= 0) { st_.jacobi_sweeps += sweeps; break; }
+        // the kernel wrote neither Ritz values nor V: nothing read back in this attempt may be used
+        st_.jacobi_barrier_timeouts++;
+        DLCO_CHECK(attempt == 0, -3, "eig tracker: the Jacobi kernel reported a failure twice (grid barrier of jacobi_mw_kernel, then the single-workgroup kernel)");
+        if (prof_) prof_->begin(PROF_JACOBI);
+        }
         std::memcpy(h_theta_.data(), pin_, (size_t)m_ * sizeof(float));
         std::memcpy(h_res_.data(), pin_ + (cap_ + 8), (size_t)m_ * sizeof(float));
-        st_.jacobi_sweeps += *reinterpret_cast<int *>(pin_ + 2 * (cap_ + 8));
         have_theta_ = true;
         {
             const int before = m_;

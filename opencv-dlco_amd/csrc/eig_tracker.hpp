@@ -21,6 +21,7 @@ namespace dlco {
 
 struct EigStats {
     int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0, cheap_passes = 0;
+    int64_t jacobi_barrier_timeouts = 0;   // multi-workgroup Jacobi calls that gave up at their grid barrier and were redone on one workgroup
 };
 
 class EigTracker {

@@ -706,9 +706,8 @@ bool skinny_product_bf16x2(const float *X, long ldx, int M, const float *G, long
     g.xcd_map = xcd_map;
     const dim3 grid(N / 128, ks), block(T8);
     // whole symmetric matrix: stream its rows through LDS (skinny_rows_kernel)
-    static const bool rows_ok = std::getenv("DLCO_PRODUCT_V1") == nullptr;
     // (four row tiles with the three-way split do not fit the register budget of the split-role kernel)
-    if (rows_ok && N == K && K % (128 * ks) == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0 &&
+    if (N == K && K % (128 * ks) == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(G) & 15) == 0 &&
         (long)K * ldg * 4 < (1L << 31) && !(mt >= 4 && plane_lo2)) {
         if (plane_lo2) {
             if (mt == 1) launch_rows<1, 3>(g, grid, s);

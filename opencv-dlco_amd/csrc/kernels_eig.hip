@@ -82,133 +82,15 @@ __global__ __launch_bounds__(256) void symv_kernel(const float *H, long ld, int 
     if (lane == 0) y[row] = s;
 }
 
-// CholQR building block: Gram matrix M (n <= 128, lower triangle read) -> Linv = L^-1 with
-// M = L L^T, on one workgroup of 16 waves.
+// CholQR building block: Gram matrix M (n <= 160, lower triangle read) -> Linv = L^-1 with M = L L^T, on one workgroup.
 //
-// Right-looking elimination without pivoting on the augmented matrix [M | I]: step j subtracts
-// (A_ij / A_jj) * row j from every row i > j.  The left half turns into the Schur complements
-// (pivot d_j = A_jj at step j), the right half into U^-1 of M = U D U^T, and L^-1 = D^-1/2 U^-1.
-// Thread (i, g) keeps 32 consecutive entries of row i of the 256-wide augmented matrix in
-// registers (g < 4: columns of M, g >= 4: columns of I); a wave is 64 rows of one column group,
-// so groups that a step cannot touch (M columns <= j, U^-1 columns > j) and rows <= j retire as
-// whole waves.  Pivot row and pivot column of the next step travel through double-buffered
-// LDS vectors: one barrier per step.  A row whose pivot drops below rel_thresh * M_jj lies (to
-// fp32 accuracy) in the span of the rows before it: it is marked dead, eliminated from nothing,
-// and its row of Linv is zero.
-constexpr int CI_T = 1024;
-
-__global__ __launch_bounds__(CI_T) void chol_inv_kernel(const float *M, long ldm, int n, float rel_thresh, float *Linv,
-                                                       long ldl, int *dead)
-{
-    __shared__ __attribute__((aligned(16))) float rowbuf[2][256];
-    __shared__ float colbuf[2][128];
-    __shared__ float diag0[128], dpiv[128];
-    __shared__ int deadf[128];
-    const int t = threadIdx.x, i = t & 127, g = t >> 7;
-    const bool is_x = g >= 4;
-    const int c0 = (g & 3) * 32;
-    float v[32];
-#pragma unroll
-    for (int c = 0; c < 32; c++) {
-        const int k = c0 + c;
-        if (is_x) v[c] = (i == k) ? 1.f : 0.f;
-        else if (i < n && k < n) v[c] = M[(long)max(i, k) * ldm + min(i, k)];
-        else v[c] = (i == k) ? 1.f : 0.f;
-    }
-    if (t < 128) diag0[t] = t < n ? M[(long)t * ldm + t] : 1.f;
-    if (i == 0) {
-#pragma unroll
-        for (int c = 0; c < 32; c++) rowbuf[0][g * 32 + c] = v[c];
-    }
-    if (g == 0) colbuf[0][i] = v[0];
-    // Fast path (second pass of CholQR2): M = I + E with |E|_F <= 1e-3.  Then M^-1/2 = I - E/2 up
-    // to 3/8 |E|^2 <= 4e-7, the symmetric orthogonaliser replaces the triangular one and the n
-    // sequential elimination steps are skipped.  (Padding entries hold the identity: E = 0 there.)
-    {
-        float e2 = 0.f;
-        if (!is_x) {
-#pragma unroll
-            for (int c = 0; c < 32; c++) { const float e = v[c] - ((i == c0 + c) ? 1.f : 0.f); e2 += e * e; }
-        }
-        e2 = wsum(e2);
-        if ((t & 63) == 0) dpiv[t >> 6] = e2;
-    }
-    __syncthreads();
-    {
-        float tot = 0.f;
-        for (int w = 0; w < CI_T / 64; w++) tot += dpiv[w];
-        __syncthreads();                                     // dpiv is reused by the elimination below
-        if (tot <= 1e-6f) {                                   // workgroup-uniform (false for NaN)
-            if (!is_x && i < n) {
-#pragma unroll
-                for (int c = 0; c < 32; c++) {
-                    const int k = c0 + c;
-                    if (k < n) Linv[(long)i * ldl + k] = ((i == k) ? 1.5f : 0.f) - 0.5f * v[c];
-                }
-            }
-            if (t < n) dead[t] = 0;
-            return;
-        }
-    }
-
-    // the step loop stays rolled: the body is executed once per step, so an unrolled copy of it
-    // would run entirely out of cold instruction-cache lines
-#pragma unroll 1
-    for (int j = 0; j < n; j++) {
-        const int buf = j & 1;
-        const float piv = rowbuf[buf][j];
-        const float d0 = diag0[j];
-        const bool is_dead = !(piv > rel_thresh * d0) || !(d0 > 0.f);
-        if (t == 0) { dpiv[j] = piv; deadf[j] = is_dead ? 1 : 0; }
-        const bool grp_active = is_x ? (c0 <= j) : (c0 + 31 > j);            // wave-uniform
-        if (!is_dead && grp_active && i > j && i < n) {
-            const float f = colbuf[buf][i] / piv;
-            const f32x4 *rp = reinterpret_cast<const f32x4 *>(&rowbuf[buf][g * 32]);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const f32x4 r = rp[q];
-                v[4 * q + 0] -= f * r[0];
-                v[4 * q + 1] -= f * r[1];
-                v[4 * q + 2] -= f * r[2];
-                v[4 * q + 3] -= f * r[3];
-            }
-        }
-        if (j + 1 < n) {                                                      // publish pivot row / column of step j+1
-            if (i == j + 1) {
-                f32x4 *wp = reinterpret_cast<f32x4 *>(&rowbuf[buf ^ 1][g * 32]);
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    f32x4 r = {v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-                    wp[q] = r;
-                }
-            }
-            if (g == ((j + 1) >> 5)) {                                        // the two waves that own column j+1 of M
-                const int cn = (j + 1) & 31;
-                float cv = v[0];
-#pragma unroll
-                for (int c = 1; c < 32; c++) cv = (c == cn) ? v[c] : cv;     // register select, no dynamic indexing
-                colbuf[buf ^ 1][i] = cv;
-            }
-        }
-        __syncthreads();
-    }
-    // Linv = D^-1/2 U^-1 (lower triangular); dead rows and the padding are zero
-    if (is_x && i < n) {
-        const bool dd = deadf[i] != 0;
-        const float sc = dd ? 0.f : rsqrtf(dpiv[i]);
-#pragma unroll
-        for (int c = 0; c < 32; c++) {
-            const int k = c0 + c;
-            if (k < n) Linv[(long)i * ldl + k] = (k <= i) ? v[c] * sc : 0.f;
-        }
-    }
-    if (t < n) dead[t] = deadf[t];
-}
-
-// ---- the same factorisation, blocked: 32 pivots per workgroup barrier instead of one ------------------
-// chol_inv_kernel pays a workgroup barrier (and an LDS broadcast of the pivot row) for every one of the
-// n sequential pivots: ~1.2 us each, 114 us at n = 96.  Here the elimination of [M | I] proceeds in
-// blocks of 32 pivots:
+// Right-looking elimination without pivoting on the augmented matrix [M | I]: step j subtracts (A_ij / A_jj) * row j
+// from every row i > j.  The left half turns into the Schur complements (pivot d_j = A_jj at step j), the right half into
+// U^-1 of M = U D U^T, and L^-1 = D^-1/2 U^-1.  A row whose pivot drops below rel_thresh * M_jj lies (to fp32 accuracy) in
+// the span of the rows before it: it is marked dead, eliminated from nothing, and its row of Linv is zero.  (Round 1's
+// kernel did this one pivot per workgroup barrier - ~1.2 us each, 114 us at n = 96; it left the library in round 4.)
+// ---- blocked: 32 pivots per workgroup barrier instead of one --------------------------------------------
+// The elimination of [M | I] proceeds in blocks of 32 pivots:
 //   1. the 32 x 32 diagonal block goes to LDS and ONE wave eliminates it in registers (lane i = row i of
 //      [D | I]; the pivot row reaches the other lanes through v_readlane, no barrier inside the 32
 //      steps), which yields the pivots d, the dead flags and the unit lower triangular T = L1^-1 of
@@ -216,10 +98,10 @@ __global__ __launch_bounds__(CI_T) void chol_inv_kernel(const float *M, long ldm
 //   2. every thread then applies the block's 32 steps at once to its entries: the block's rows become
 //      P = T * rows, the multipliers of the rows below are F = (A[:,K] T^T) / d (the Schur complement
 //      is symmetric, so U_KK^-1 = T^T D^-1), and the trailing update is the rank-32 product F * P.
-// The matrix stays in registers as in chol_inv_kernel (thread (ty, tx) holds rows ty + 32 r, columns
-// tx + 32 c of [M | I]); LDS only carries the block's rows, columns, T, P and F.  Four barriers per
-// block of 32 pivots.  Same result up to rounding (the multipliers are a[j] * rcp(d) instead of a[j] / d;
-// CholQR2's second pass absorbs that), same dead-row rule, same fast path for M = I + E.
+// The matrix stays in registers (thread (ty, tx) holds rows ty + 32 r, columns tx + 32 c of [M | I]); LDS only
+// carries the block's rows, columns, T, P and F.  Four barriers per block of 32 pivots.  The multipliers are
+// a[j] * rcp(d) instead of a[j] / d (CholQR2's second pass absorbs that).  Fast path for M = I + E with
+// |E|_F^2 <= 1e-6 (the second pass of CholQR2): M^-1/2 = I - E/2, no elimination.
 // NBM = blocks of 32 rows the kernel is built for: 4 (n <= 128) or 5 (n <= 160: the block of the rank ~128 workload in ONE
 // orthonormalisation panel instead of two panels with a Gram-Schmidt step between them; 50 registers of matrix per thread).
 constexpr int C2_T = 1024;
@@ -262,7 +144,7 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
             reg[r][NBM + c] = (i == k) ? 1.f : 0.f;
         }
     if (t < NR) { diag0[t] = t < n ? M[(long)t * ldm + t] : 1.f; deadf[t] = 0; dpiv[t] = 1.f; }
-    // Fast path (second pass of CholQR2): M = I + E with |E|_F^2 <= 1e-6 -> M^-1/2 = I - E/2 (see chol_inv_kernel)
+    // Fast path (second pass of CholQR2): M = I + E with |E|_F^2 <= 1e-6 -> M^-1/2 = I - E/2 
     {
         float e2 = 0.f;
 #pragma unroll
@@ -432,9 +314,7 @@ static void launch_chol_inv2(const float *M, long ldm, int n, float rel_thresh, 
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
 {
     DLCO_CHECK(n >= 1 && n <= CHOL_INV_MAX_N, -2, "chol_inverse128: n out of range");
-    static const bool use_v1 = std::getenv("DLCO_CHOL_V1") != nullptr;
-    if (use_v1 && n <= 128) hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(CI_T), 0, s, M, ldm, n, rel_thresh, Linv, ldl, dead);
-    else if (n <= 128) launch_chol_inv2<4>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
+    if (n <= 128) launch_chol_inv2<4>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
     else launch_chol_inv2<5>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
     DLCO_HIP(hipGetLastError());
 }

@@ -736,8 +736,28 @@ inline int col_stride(int n) { return (n + 3) & ~3; }
 
 size_t jacobi_work_floats(int n) { return std::max((size_t)n * col_stride(n) + 4 * (size_t)n + 64, n <= JMW_MAX_N ? jmw_work_floats(n) : (size_t)0); }
 
+// can the grid of the multi-workgroup kernel be resident all at once on this device?  (its barrier needs that; the
+// bounded wait catches what this cannot know: another stream's kernels holding the CUs)
+static bool jmw_fits(int nwg, size_t lds)
+{
+    struct Entry { int dev; size_t lds; long slots; };
+    static std::vector<Entry> cache;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+        if (e.dev == dev && e.lds == lds) return e.slots >= nwg;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(jacobi_mw_kernel), JMW_T, lds) != hipSuccess) return false;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    cache.push_back({dev, lds, (long)per_cu * prop.multiProcessorCount});
+    return cache.back().slots >= nwg;
+}
+
 void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long ldv, float *work, int *sweeps_out,
-                 hipStream_t s, float lam_cut)
+                 hipStream_t s, float lam_cut, bool single_workgroup)
 {
     DLCO_CHECK(n >= 1 && n <= 4096, -2, "jacobi_eigh: n out of range");
     // largest column cosine of a sweep below which the sweep is the last one (see jacobi_body)
@@ -747,7 +767,9 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         if (e == 1) launch_jacobi_blk<1>(T, ldt, n, evals, V, ldv, sweeps_out, stop_cos, lam_cut, s);
         else if (e == 3) launch_jacobi_blk<3>(T, ldt, n, evals, V, ldv, sweeps_out, stop_cos, lam_cut, s);
         else launch_jacobi_blk<5>(T, ldt, n, evals, V, ldv, sweeps_out, stop_cos, lam_cut, s);
-    } else if (n <= JMW_MAX_N) {
+    } else if (n <= JMW_MAX_N && !single_workgroup &&
+               (ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_mw_kernel), 160 * 1024 - 1024),
+                jmw_fits(jmw_nbe(n) / 2, ((size_t)16 * jmw_ldc(n) + 128) * sizeof(float)))) {
         // many CUs, one workgroup per block pair; the grid barrier's words sit behind the work image and are cleared per call
         JmwDev g;
         g.T = T; g.ldt = ldt; g.n = n; g.evals = evals; g.Vout = V; g.ldv = ldv;
@@ -758,9 +780,11 @@ void jacobi_eigh(const float *T, long ldt, int n, float *evals, float *V, long l
         // the caller's workspace, so two trackers on two streams never share a barrier
         unsigned *sync_words = reinterpret_cast<unsigned *>(work + ncol * g.ldc + 2 * ncol);
         DLCO_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
+        // test hook: raise the barrier's give-up flag before the launch, every workgroup then leaves at its first grid barrier
+        static const bool force_timeout = std::getenv("DLCO_TEST_JMW_TIMEOUT") != nullptr;
+        if (force_timeout) DLCO_HIP(hipMemsetAsync(sync_words + 1, 1, 1, s));
         g.sync = sync_words; g.sweeps_out = sweeps_out; g.stop_cos = stop_cos; g.lam_cut = lam_cut;
         const size_t lds = ((size_t)16 * g.ldc + 128) * sizeof(float);
-        ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_mw_kernel), 160 * 1024 - 1024);
         hipLaunchKernelGGL(jacobi_mw_kernel, dim3(g.nbe / 2), dim3(JMW_T), lds, s, g);
     } else {
         hipLaunchKernelGGL(jacobi_gmem_kernel<512>, dim3(1), dim3(512), 0, s, T, ldt, n, col_stride(n), evals, V, ldv, work, sweeps_out, stop_cos, lam_cut);

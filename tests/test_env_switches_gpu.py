@@ -1,0 +1,121 @@
+"""The library's developer switches are read once per process (getenv), so each one gets a child process: the code
+behind a switch - the fp32-MFMA gradient kernel `syrk_rda_kernel8` (the k-ordered v_mfma_f32_32x32x2_f32 chain that
+north_star literally names), the fp32 filter / Rayleigh-Ritz products, the unpacked dual average, the recovery from a
+grid-barrier time-out of the multi-workgroup Jacobi - is held to the same oracle gates as the default path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(case):
+    """Runs in the child: same bodies and gates as tests/test_gpu_parity.py."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch  # noqa: F401  (first HIP runtime in the process, see conftest.py)
+    dlco = importlib.import_module("opencv-dlco_amd")
+    from oracle import ref
+    from util import relmax, synth
+    ref.lib()
+    TOL_DIST, TOL_GRAD, TOL_A = 2e-5, 5e-6, 1e-4
+
+    def grad_case(F, B, zero_frac):
+        N = 1500
+        D, L = synth(N, F, k=12, seed=F + B)
+        ctx = dlco.Context(F, N, B=B, mu=0.004, gamma=0.5)
+        ctx.set_data(D, L)
+        rng = np.random.default_rng(B)
+        pr, nr = rng.integers(0, N, B).astype(np.int32), rng.integers(0, N, B).astype(np.int32)
+        rho, kap = rng.integers(0, 6, B).astype(np.int32), rng.integers(0, 6, B).astype(np.int32)
+        rho[rng.random(B) < zero_frac] = 0
+        kap[rng.random(B) < zero_frac] = 0
+        G0 = rng.standard_normal((F, F)).astype(np.float32)
+        G0 = (G0 + G0.T) * np.float32(0.5)
+        got = ctx.grad_rda(pr, nr, rho, kap, 0.3, 0.9, G0)
+        P, Nn = D[pr].astype(np.float64), D[nr].astype(np.float64)
+        want = 0.9 * G0 + 0.3 * ((P * rho[:, None]).T @ P - (Nn * kap[:, None]).T @ Nn)
+        e = relmax(got, want)
+        assert e <= TOL_GRAD, (F, B, e)
+        ctx.close()
+        return e
+
+    def teacher_forced(F, B, nstep, N=4000, expect_timeouts=False):
+        D, L = synth(N, F, k=20, seed=9)
+        mu, gamma = 0.004, 0.5
+        tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+        ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+        ctx.set_data(D, L)
+        checked, worst = 0, 0.0
+        for s in range(nstep):
+            before = tr.state()
+            tr.step()
+            after = tr.state()
+            ctx.set_state(s, before["dfavg"], before["W"] if s else None)
+            ctx.step()
+            b = ctx.batch()
+            pr, nr = tr.batch_ids()
+            assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+            pd, nd = tr.batch_dists()
+            scale = max(pd.max(), nd.max(), 1e-30)
+            assert np.abs(b["pd"] - pd).max() <= TOL_DIST * scale and np.abs(b["nd"] - nd).max() <= TOL_DIST * scale
+            rho, kap = ref.viol_counts(pd, nd)
+            if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
+                assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
+                e = relmax(ctx.A(), after["A"])
+                worst = max(worst, e)
+                assert e <= TOL_A, (s, e)
+                checked += 1
+        assert checked >= nstep - 2, checked
+        cn = ctx.counters()
+        assert cn["nonconverged"] == 0
+        if expect_timeouts:
+            assert cn["jacobi_barrier_timeouts"] >= 1, cn
+        else:
+            assert cn["jacobi_barrier_timeouts"] == 0, cn
+        ctx.close()
+        tr.close()
+        return worst
+
+    if case == "syrk_fp32":
+        for F, B, z in ((128, 8, 0.0), (256, 200, 0.3), (384, 33, 0.9), (544, 200, 0.2)):
+            print("grad_rda F=%d B=%d: %.2e" % (F, B, grad_case(F, B, z)))
+        print("teacher forced: %.2e" % teacher_forced(256, 200, 8))
+    elif case in ("fp32_products", "no_packed"):
+        print("teacher forced F=512: %.2e" % teacher_forced(512, 200, 10))
+        print("teacher forced F=544: %.2e" % teacher_forced(544, 200, 6))
+    elif case == "jmw_timeout":
+        # step 0 of a batch of 200 + 200 seeds the block with 400 rows: the multi-workgroup Jacobi's size class
+        print("teacher forced with forced barrier time-outs: %.2e" % teacher_forced(512, 200, 3, expect_timeouts=True))
+    else:
+        raise SystemExit("unknown case " + case)
+    print("child ok")
+
+
+CASES = {
+    "syrk_fp32": {"DLCO_SYRK_FP32": "1"},
+    "fp32_products": {"DLCO_FP32_FILTER": "1", "DLCO_FP32_RR": "1"},
+    "no_packed": {"DLCO_NO_PACKED": "1"},
+    "jmw_timeout": {"DLCO_TEST_JMW_TIMEOUT": "1"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_switch_in_a_child_process(case):
+    env = dict(os.environ)
+    env.update(CASES[case])
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case], capture_output=True, text=True, timeout=600, env=env)
+    print(p.stdout)
+    assert p.returncode == 0 and "child ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--child":
+        _child(sys.argv[2])
+    else:
+        raise SystemExit("usage: test_env_switches_gpu.py --child <case>")

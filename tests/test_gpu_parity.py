@@ -301,6 +301,7 @@ def test_teacher_forced_steps_golden(dlco, ref, fname):
     N, F, B, nstep = int(N), int(F), int(B), int(nstep)
     ctx = dlco.Context(F, N, B=B, mu=float(mu), gamma=float(gamma))
     ctx.set_data(z["D"], z["L"])
+    checked = 0
     for s in range(nstep):
         W_in = z["s%d_W_in" % s]
         if s == 0:
@@ -318,6 +319,9 @@ def test_teacher_forced_steps_golden(dlco, ref, fname):
         if np.array_equal(rho, z["s%d_rho" % s]) and np.array_equal(kap, z["s%d_kappa" % s]):
             assert relmax(ctx.dfavg(), z["s%d_dfavg" % s]) <= TOL_GRAD * 4
             _check_A("teacher-forced golden " + fname, ctx.A(), z["s%d_A" % s])
+            checked += 1
+    # a distance within an ulp of a margin may flip one count in one step; more than that is a regression, not rounding
+    assert checked >= nstep - 1, (checked, nstep)
     ctx.close()
 
 
