@@ -787,8 +787,8 @@ int dlco_get_index(const dlco_ctx *c, int32_t *pos, int32_t *n_pos, int32_t *n_p
                    int32_t *n_neg_trn)
 {
     if (!c || !c->have_data) return DLCO_ERR_INVALID;
-    if (pos) std::memcpy(pos, c->idx.pos.data(), c->idx.pos.size() * sizeof(int32_t));
-    if (neg) std::memcpy(neg, c->idx.neg.data(), c->idx.neg.size() * sizeof(int32_t));
+    if (pos && !c->idx.pos.empty()) std::memcpy(pos, c->idx.pos.data(), c->idx.pos.size() * sizeof(int32_t));
+    if (neg && !c->idx.neg.empty()) std::memcpy(neg, c->idx.neg.data(), c->idx.neg.size() * sizeof(int32_t));
     if (n_pos) *n_pos = (int32_t)c->idx.pos.size();
     if (n_neg) *n_neg = (int32_t)c->idx.neg.size();
     if (n_pos_trn) *n_pos_trn = c->idx.n_pos_trn;

@@ -12,8 +12,8 @@ int shim_build_index(const uint8_t *labels, int N, int32_t *pos, int *n_pos, int
 {
     dlco::PairIndex idx;
     idx.build(labels, N);
-    std::memcpy(pos, idx.pos.data(), idx.pos.size() * sizeof(int32_t));
-    std::memcpy(neg, idx.neg.data(), idx.neg.size() * sizeof(int32_t));
+    if (!idx.pos.empty()) std::memcpy(pos, idx.pos.data(), idx.pos.size() * sizeof(int32_t));
+    if (!idx.neg.empty()) std::memcpy(neg, idx.neg.data(), idx.neg.size() * sizeof(int32_t));
     *n_pos = (int)idx.pos.size(); *n_neg = (int)idx.neg.size();
     *n_pos_trn = idx.n_pos_trn; *n_neg_trn = idx.n_neg_trn;
     return 0;
