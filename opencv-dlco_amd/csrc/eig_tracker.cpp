@@ -122,7 +122,7 @@ void EigTracker::product(const float *X, int rows, const float *G, float alpha, 
     // (the row-streaming kernel takes 160 rows with the two-way split - a block of rank ~128 plus its guards
     // in ONE pass over G - and 96 with the three-way split; a sharded rank's slab kernel 128)
     const int one_pass = (approx && !shard_ && bf16_filter_) ? 160 : (packed_ ? 96 : 128);   // (symmetric three-way kernel: 96 rows)
-    if (rows > one_pass && bf16_filter_ && F_ >= 256 && (approx || plane_lo2_.p)) {
+    if (rows > one_pass && bf16_filter_ && (packed_ || F_ >= 256) && (approx || plane_lo2_.p)) {
         chain_next_ = false;                                     // row chunks share the plane buffers: no carried planes
         const int step = approx ? (rows <= 2 * one_pass ? (rows / 2 + 31) / 32 * 32 : one_pass) : 96;
         for (int r0 = 0; r0 < rows; r0 += step) {

@@ -459,7 +459,9 @@ struct SymDev {
     float *slab;                  // [4][M][K] raw partial sums
 };
 
-template <int MT, int NS>
+// FULL: the tile count is the power of two itself (K = 8192: 64 tile rows) - every partner is real and comes from bit
+// arithmetic alone, no list in LDS inside the loop.
+template <int MT, int NS, bool FULL>
 __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -484,7 +486,8 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
     if (I >= NT) return;                                       // a block of the padding: the whole workgroup leaves
     const int dbase = (p == 0 ? 1 : (p == 1 ? 2 : (p == 2 ? 3 : 0))) << (lb - 2);
     int nchunks;                                               // real partner tiles x 2 halves of 64 k
-    {
+    if (FULL) nchunks = 2 << (lb - 2);
+    else {
         const int nslots = 1 << (lb - 2);
         int cnt = 0;
         for (int sl = 0; sl < nslots; sl++) {
@@ -492,10 +495,17 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
             if (J < NT) { if (tid == 0) jlist[cnt] = J; cnt++; }
         }
         nchunks = 2 * cnt;
+        __syncthreads();
     }
-    __syncthreads();
+    if (!FULL && nchunks == 0) {
+        // no real partner in this group (only possible beside padding blocks): the group's slab still has to hold zeros
+        // for this block's columns, the reduction adds all four
+        float *slab = g.slab + (long)p * g.M * g.K;
+        for (int e = tid; e < g.M * 128; e += RK_T) slab[(long)(e >> 7) * g.K + I * 128 + (e & 127)] = 0.f;
+        return;
+    }
     // chunk cc: partner block, orientation, byte offset of the stored tile
-    auto partner = [&](int cc) { return jlist[cc >> 1]; };
+    auto partner = [&](int cc) { return FULL ? (I ^ (dbase | (cc >> 1))) : jlist[cc >> 1]; };
     auto tile_bytes = [&](int J) {
         const int a = min(I, J), b = max(I, J);
         return (a * NT - a * (a - 1) / 2 + (b - a)) * (128 * 128 * (int)sizeof(float));
@@ -516,19 +526,29 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
         const __amdgpu_buffer_rsrc_t rs_lo2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(NS == 3 ? g.xlo2 : g.xlo), 0, plane_bytes, 0x00020000);
         struct Stage { f32x4 gq[8]; bf16x8 aq[NA]; };
         Stage s0, s1;
+        // The loads of a chunk are issued in ONE fixed order (G then X planes, fenced against the scheduler): hipcc places
+        // its s_waitcnt from a per-register model that is merged conservatively at the loop header, and when the prologue
+        // issues a set's loads in another order than the loop body does, the merged state makes a store in the loop wait
+        // for the YOUNGEST load in flight (vmcnt(0): the chunk requested one barrier ago) instead of its own (vmcnt(14+)) -
+        // the prefetch distance collapses to one chunk (seen in the ISA of round 3's kernel).
         auto gload = [&](int cc, Stage &st) {
             const int J = __builtin_amdgcn_readfirstlane(partner(cc)), half = cc & 1;
             const bool direct = I <= J;
             const int voff = direct ? voff_d : voff_t;
             const int soff = tile_bytes(J) + (direct ? half * 64 : half * 64 * 128) * (int)sizeof(float);
             const int ustep = (direct ? 16 : 8) * 128 * (int)sizeof(float);
-#pragma unroll
-            for (int u = 0; u < 8; u++) st.gq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + u * ustep, 0));
             const int a0 = (J * 8 + half * 4) * MT * 64 * 16;  // the X planes' slice for block J, this half: byte offset inside a plane
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                st.gq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + u * ustep, 0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int v = 0; v < NA; v++) {
                 const __amdgpu_buffer_rsrc_t &ra = (v / MT == 0) ? rs_hi : ((v / MT == 1) ? rs_lo : rs_lo2);
                 st.aq[v] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, 16 * lt, a0 + (v % MT) * 256 * 16, 0));
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto gstore = [&](int cc, const Stage &st) {                 // into image cc & 1
@@ -543,13 +563,13 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
         };
         // chunk q: multiplied in iteration q, copied to image q & 1 at the start of iteration q - 1, requested at iteration
         // q - 3 into register set q & 1 (chunks 0..2 before the loop); no branch around a load in the steady state
-        // (nchunks is even; a workgroup without a real partner - nchunks = 0 - only joins the barriers)
-        if (nchunks > 0) {
-            gload(0, s0);
-            gload(1, s1);
-            gstore(0, s0);
-            if (nchunks > 2) gload(2, s0);
-        }
+        // (nchunks is even and >= 2 here; the prologue is unconditional - chunk 2 is clamped to the last one, a harmless
+        // re-load when there are only two - because a branch around a load would again leave the loop header with a
+        // merged, conservative wait state)
+        gload(0, s0);
+        gload(1, s1);
+        gstore(0, s0);
+        gload(min(2, nchunks - 1), s0);
         __syncthreads();
         int cc = 0;
         for (; cc + 4 < nchunks; cc += 2) {
@@ -557,10 +577,14 @@ __global__ __launch_bounds__(RK_T) void skinny_sym_kernel(SymDev g)
             gstore(cc + 2, s0); gload(cc + 4, s0); __syncthreads();
         }
         // tail: iterations cc .. nchunks - 1 (cc = nchunks - 4 when nchunks >= 4, else 0), the same sequence with guards
-        for (; cc < nchunks; cc++) {
-            Stage &set = ((cc + 1) & 1) ? s1 : s0;
-            if (cc + 1 < nchunks) gstore(cc + 1, set);
-            if (cc + 3 < nchunks) gload(cc + 3, set);
+        // (cc is even here and so is nchunks: iterations in pairs, each with its own register set - a set chosen at run time
+        // would put both into scratch memory)
+        for (; cc < nchunks; cc += 2) {
+            if (cc + 1 < nchunks) gstore(cc + 1, s1);
+            if (cc + 3 < nchunks) gload(cc + 3, s1);
+            __syncthreads();
+            if (cc + 2 < nchunks) gstore(cc + 2, s0);
+            if (cc + 4 < nchunks) gload(cc + 4, s0);
             __syncthreads();
         }
         __syncthreads();                                           // the compute waves' K-half exchange
@@ -658,8 +682,13 @@ template <int MT, int NS>
 void launch_sym(const SymDev &g, hipStream_t s)
 {
     const size_t lds = rk_lds_bytes(MT, NS);
-    ensure_dynamic_lds(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS>), (int)lds);
-    hipLaunchKernelGGL((skinny_sym_kernel<MT, NS>), dim3(4u << g.lb), dim3(RK_T), lds, s, g);
+    if (g.nt == (1 << g.lb)) {
+        ensure_dynamic_lds(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS, true>), (int)lds);
+        hipLaunchKernelGGL((skinny_sym_kernel<MT, NS, true>), dim3(4u << g.lb), dim3(RK_T), lds, s, g);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void *>(skinny_sym_kernel<MT, NS, false>), (int)lds);
+        hipLaunchKernelGGL((skinny_sym_kernel<MT, NS, false>), dim3(4u << g.lb), dim3(RK_T), lds, s, g);
+    }
 }
 
 template <int MT, int NS>
