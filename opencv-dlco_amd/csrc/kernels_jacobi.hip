@@ -17,6 +17,9 @@
 // workgroup on an L2-resident image.  All of them return the eigenvectors as the ROWS of V.
 #include "dlco_internal.hpp"
 
+#include <cstdio>
+#include <vector>
+
 #include <algorithm>
 
 namespace dlco {
@@ -274,10 +277,16 @@ inline size_t jblk_lds_bytes(int n) { const int ncol = 16 * jblk_waves(n); retur
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int E>
+// TR (developer aid, DLCO_JACOBI_TRACE=file): lane 0 of wave 1 stamps s_memtime at four points of every inner rotation step
+template <int E, bool TR = false>
 __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
-                                                         int *sweeps_out, float stop_cos, float lam_cut)
+                                                         int *sweeps_out, float stop_cos, float lam_cut, unsigned long long *trace = nullptr)
 {
+    int tri = 0;
+    bool tron = false;                                         // stamps only while the blocks meet (four per inner step)
+    auto stamp = [&]() {
+        if (TR && tron && threadIdx.x == 64 && tri < 4096) trace[tri++] = __builtin_amdgcn_s_memtime();
+    };
     constexpr int LDC = 32 * E, P = 2 * E;
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
         for (int p = 2; p < P; p += 2) { acc0 += x[p] * y[p]; acc1 += x[p + 1] * y[p + 1]; }
         acc0 += acc1;
         const float c = row8_sum(acc0[0] + acc0[1]) * ssab;
+        if (TR) { asm volatile("" :: "v"(c)); stamp(); }
         const float off = fabsf(c) * rab;
         off_max = fmaxf(off_max, fmaxf(a, b) > cut2 ? off : 0.f);
         const bool rot = off > tol;
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
         }
         __syncthreads();
         // ---- the blocks meet: round r pairs block m with block r, and (r + k) mod m with (r - k) mod m ---------------
+        tron = true;
         for (int r = 0; r < m; r++) {
             const int ba = wave == 0 ? m : (r + wave) % m, bb = wave == 0 ? r : (r - wave + m) % m;
             const int ca = 8 * ba + g;
@@ -445,16 +456,19 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
             bool touched = false;
 #pragma unroll 1
             for (int kk = 0; kk < 8; kk++) {
+                stamp();
                 const int cb = 8 * bb + ((g + kk) & 7);
                 load_col(cb, y);
                 const f32x2 rb = rec[cb];
                 float b = rb[0], sb = rb[1];
+                if (TR) { __builtin_amdgcn_s_waitcnt(0xc07f); stamp(); }          // lgkmcnt(0): the partner column is in
                 if (sb < small || sb > big) multiply_out(y, sb);
                 if (rotate(x, y, a, sa, rsa, b, sb, __builtin_amdgcn_rcpf(sb))) {
+                    if (TR) { asm volatile("" :: "v"(y[0][0])); stamp(); }
                     store_col(cb, y);
                     if (l == 0) rec[cb] = f32x2{b, sb};
                     touched = true;
-                }
+                } else if (TR) stamp();
             }
             if (touched) {
                 store_col(ca, x);
@@ -462,6 +476,7 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
             }
             __syncthreads();
         }
+        tron = false;
         off_max = wmax(off_max);
         if (lane == 0) red[wave] = off_max;
         __syncthreads();
@@ -503,6 +518,26 @@ void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, 
                        hipStream_t s)
 {
     ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_blk_kernel<E>), 160 * 1024 - 1024);
+    static const char *trace_path = std::getenv("DLCO_JACOBI_TRACE");
+    static int calls = 0;
+    if (trace_path && E == 3 && ++calls == 300) {               // one call in the steady state of a bench run
+        unsigned long long *buf = nullptr;
+        DLCO_HIP(hipMalloc((void **)&buf, 4096 * 8));
+        DLCO_HIP(hipMemsetAsync(buf, 0, 4096 * 8, s));
+        ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_blk_kernel<E, true>), 160 * 1024 - 1024);
+        hipLaunchKernelGGL((jacobi_blk_kernel<E, true>), dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv,
+                           sweeps_out, stop_cos, lam_cut, buf);
+        DLCO_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(4096);
+        DLCO_HIP(hipMemcpy(h.data(), buf, 4096 * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(buf);
+        if (FILE *f = std::fopen(trace_path, "w")) {
+            std::fprintf(f, "# n = %d; per inner rotation step of wave 1: top, partner column in, dot product reduced, updates done (s_memtime)\n", n);
+            for (int i = 0; i + 3 < 4096 && h[i]; i += 4) std::fprintf(f, "%llu %llu %llu %llu\n", h[i], h[i + 1], h[i + 2], h[i + 3]);
+            std::fclose(f);
+        }
+        return;
+    }
     hipLaunchKernelGGL(jacobi_blk_kernel<E>, dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv,
                        sweeps_out, stop_cos, lam_cut);
 }

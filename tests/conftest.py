@@ -29,4 +29,9 @@ def ref():
     """The CPU oracle (test infrastructure)."""
     from oracle import ref as r
     r.lib()
+    # One thread: the oracle's problems in this suite are small (F <= 608) and its OpenMP / OpenBLAS teams cost more than
+    # they give there - with every core of the box, a 64-wide step took 22 ms instead of 1.3 ms and a 544-wide one 96 ms
+    # instead of 57 ms (the free-run tests were 580 of the GPU suite's 860 s).  The full-width tests (ssyevr at n = 8192)
+    # raise it themselves and put it back.
+    r.set_threads(1)
     return r

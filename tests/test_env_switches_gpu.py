@@ -22,6 +22,7 @@ def _child(case):
     from oracle import ref
     from util import relmax, synth
     ref.lib()
+    ref.set_threads(1)                                    # small problems: see tests/conftest.py
     TOL_DIST, TOL_GRAD, TOL_A = 2e-5, 5e-6, 1e-4
 
     def grad_case(F, B, zero_frac):

@@ -51,8 +51,9 @@ TOL_FPR = 1e-3
 def _oracle_W(ref, dfavg, mu, gamma, t_last):
     """The reference's W for the dual average `dfavg` of iteration t_last (src/pj-learn.cpp:426-490)."""
     A = ref.dual_to_primal(dfavg, mu, gamma, t_last)
-    ref.set_threads(len(os.sched_getaffinity(0)))
+    ref.set_threads(len(os.sched_getaffinity(0)))         # ssyevr at n = 8192: every core (the suite's default is one thread)
     W, ev = ref.psd_factor(A)
+    ref.set_threads(1)
     del A
     return W, ev
 

@@ -204,6 +204,17 @@ int main(int argc, char **argv)
             const float b = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 3200, F, 1e-3f, 0.5f, C.p, F, s, cw, cw); });
             std::printf("syrk K=%4d  symmetric full %.1f us   column slab 1/%d (dense) %.1f us\n", K, a * 1e3, world, b * 1e3);
         }
+        // the per-rank kernels of the same-global-batch (strong scaling) mode at G = 2, 4, 8: column slab of the gradient over the
+        // 305 active rows of the c2 step, slab of a 96-row tracker product (the projection's inputs)
+        for (int G : {2, 4, 8}) {
+            const int cwg = F / G, K = 305;
+            hipMemcpy(kd.p, &K, 4, hipMemcpyHostToDevice);
+            const float a = time_ms(s, 20, [&] { syrk_rda_f32(D.p, F, ids.p, nullptr, w.p, kd.p, 416, F, 1e-3f, 0.5f, C.p, F, s, cwg, cwg); });
+            const float b = time_ms(s, 20, [&] { skinny_product_bf16x2(X.p, F, 96, C.p + cwg, F, cwg, F, 1.f, out.p + cwg, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s, 4 * G); });
+            const float e = time_ms(s, 20, [&] { pack_cols(slab.p, out.p, F, cwg, cwg, 96, s); unpack_cols(out.p, F, slab.p, cwg, 96, G, s); });
+            std::printf("G=%d: gradient column slab (K = 305 active rows, %d dense tiles) %.1f us; product slab 96 x 8192 x %d (two-way, ks %d) %.1f us; pack + unpack %.1f us\n",
+                        G, (F / 128) * (cwg / 128), a * 1e3, cwg, 4 * G, b * 1e3, e * 1e3);
+        }
         for (int M : {96}) {
             const float a = time_ms(s, 20, [&] { skinny_product_bf16x2(X.p, F, M, C.p, F, F, F, 1.f, out.p, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s); });
             const float b = time_ms(s, 20, [&] { skinny_product_bf16x2(X.p, F, M, C.p + cw, F, cw, F, 1.f, out.p + cw, F, nullptr, 0.f, nullptr, 0.f, ph.p, pl.p, slab.p, s, 32); });
