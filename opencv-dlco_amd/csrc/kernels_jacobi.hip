@@ -280,7 +280,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // TR (developer aid, DLCO_JACOBI_TRACE=file): lane 0 of wave 1 stamps s_memtime at four points of every inner rotation step
 template <int E, bool TR = false>
 __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ldt, int n, float *evals, float *Vout, long ldv,
-                                                         int *sweeps_out, float stop_cos, float lam_cut, unsigned long long *trace = nullptr)
+                                                         int *sweeps_out, float stop_cos, float lam_cut, float rot_tol,
+                                                         unsigned long long *trace = nullptr)
 {
     int tri = 0;
     bool tron = false;                                         // stamps only while the blocks meet (four per inner step)
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
     for (int j = tid; j < n; j += nthr) G[(size_t)j * LDC + j] += sigma;
     __syncthreads();
 
-    const float tol = 3e-6f, small = 9.5367431640625e-7f, big = 1048576.f;      // 2^-20, 2^20
+    const float tol = rot_tol, small = 9.5367431640625e-7f, big = 1048576.f;     // 2^-20, 2^20
     const int g = lane >> 3, l = lane & 7;
     float off_max = 0.f;
     auto load_col = [&](int col, f32x2 (&x)[P]) {
@@ -462,7 +463,12 @@ __global__ __launch_bounds__(640) void jacobi_blk_kernel(const float *T, long ld
                 const f32x2 rb = rec[cb];
                 float b = rb[0], sb = rb[1];
                 if (TR) { __builtin_amdgcn_s_waitcnt(0xc07f); stamp(); }          // lgkmcnt(0): the partner column is in
-                if (sb < small || sb > big) multiply_out(y, sb);
+                // (a wave-uniform branch: written as a plain `if`, hipcc if-converted the rare rescaling into six packed
+                // multiplies and twelve selects executed in EVERY step of this issue-bound chain)
+                if (__builtin_amdgcn_ballot_w64(sb < small || sb > big) != 0ull) {
+                    asm volatile("" ::: "memory");                                 // (keeps the branch a branch)
+                    if (sb < small || sb > big) multiply_out(y, sb);
+                }
                 if (rotate(x, y, a, sa, rsa, b, sb, __builtin_amdgcn_rcpf(sb))) {
                     if (TR) { asm volatile("" :: "v"(y[0][0])); stamp(); }
                     store_col(cb, y);
@@ -518,15 +524,17 @@ void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, 
                        hipStream_t s)
 {
     ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_blk_kernel<E>), 160 * 1024 - 1024);
+    // column cosine below which a pair is not rotated
+    static const float rot_tol = std::getenv("DLCO_JACOBI_ROT") ? (float)std::atof(std::getenv("DLCO_JACOBI_ROT")) : 3e-6f;
     static const char *trace_path = std::getenv("DLCO_JACOBI_TRACE");
     static int calls = 0;
-    if (trace_path && E == 3 && ++calls == 300) {               // one call in the steady state of a bench run
+    if (trace_path && E == 3 && ++calls == 40) {                // one call in the steady state of a bench run
         unsigned long long *buf = nullptr;
         DLCO_HIP(hipMalloc((void **)&buf, 4096 * 8));
         DLCO_HIP(hipMemsetAsync(buf, 0, 4096 * 8, s));
         ensure_dynamic_lds(reinterpret_cast<const void *>(jacobi_blk_kernel<E, true>), 160 * 1024 - 1024);
         hipLaunchKernelGGL((jacobi_blk_kernel<E, true>), dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv,
-                           sweeps_out, stop_cos, lam_cut, buf);
+                           sweeps_out, stop_cos, lam_cut, rot_tol, buf);
         DLCO_HIP(hipStreamSynchronize(s));
         std::vector<unsigned long long> h(4096);
         DLCO_HIP(hipMemcpy(h.data(), buf, 4096 * 8, hipMemcpyDeviceToHost));
@@ -539,7 +547,7 @@ void launch_jacobi_blk(const float *T, long ldt, int n, float *evals, float *V, 
         return;
     }
     hipLaunchKernelGGL(jacobi_blk_kernel<E>, dim3(1), dim3(64 * jblk_waves(n)), jblk_lds_bytes(n), s, T, ldt, n, evals, V, ldv,
-                       sweeps_out, stop_cos, lam_cut);
+                       sweeps_out, stop_cos, lam_cut, rot_tol);
 }
 
 // ---- 160 < n <= 2048: the same blocks, one workgroup per block pair, MANY CUs ----------------------------------------
