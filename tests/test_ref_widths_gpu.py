@@ -108,6 +108,69 @@ def test_free_run_band_at_544(dlco, ref):
     tr.close()
 
 
+def test_full_size_reference_shape_500000_x_544(dlco, ref):
+    """The reference's run at its own size - `Load Distances: 500000 x 544`, 200 000 + 200 000 training rows, 50 000 + 50 000
+    validation rows, batch 200 + 200, mu 0.001, gamma 0.1: the six count lines, teacher-forced steps against the oracle, then
+    150 free-running steps of both trainers inside the metric's bands and the LogStep block over all 500 000 rows with the
+    GPU's W scored by both sides."""
+    N, F, B, mu, gamma = 500000, 544, 200, 0.001, 0.1
+    rng = np.random.default_rng(544)
+    U = np.linalg.qr(rng.standard_normal((F, 64)))[0].T.astype(np.float32)
+    L = (np.arange(N) % 2 == 0).astype(np.uint8)
+    D = np.empty((N, F), np.float32)
+    for r0 in range(0, N, 50000):                                        # (in slices: the float64 temporaries stay small)
+        r1 = r0 + 50000
+        z = rng.standard_normal((r1 - r0, 64)).astype(np.float32) * np.where(L[r0:r1, None] == 1, 0.8, 1.0).astype(np.float32)
+        D[r0:r1] = np.clip(z @ U + 0.25 * rng.standard_normal((r1 - r0, F)).astype(np.float32), -1, 1)
+    tr = ref.Trainer(D, L, B=B, mu=mu, gamma=gamma, grad_order=1)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    idx = ctx.index()
+    assert (idx["pos"].size, idx["neg"].size, idx["n_pos_trn"], idx["n_neg_trn"]) == (250000, 250000, 200000, 200000)   # ...pj.log:5-10
+    ipos, ineg = ref.build_index(L)
+    assert np.array_equal(idx["pos"], ipos) and np.array_equal(idx["neg"], ineg)       # R1 at full size, bit-exact
+    checked = 0
+    for s in range(6):
+        before = tr.state()
+        tr.step()
+        after = tr.state()
+        ctx.set_state(s, before["dfavg"], before["W"] if s else None)
+        ctx.step()
+        b = ctx.batch()
+        pr, nr = tr.batch_ids()
+        assert np.array_equal(b["pos_rows"], pr) and np.array_equal(b["neg_rows"], nr)
+        pd, nd = tr.batch_dists()
+        scale = max(pd.max(), nd.max(), 1e-30)
+        assert np.abs(b["pd"] - pd).max() <= TOL_DIST * scale and np.abs(b["nd"] - nd).max() <= TOL_DIST * scale
+        rho, kap = ref.viol_counts(pd, nd)
+        if np.array_equal(b["rho"], rho) and np.array_equal(b["kappa"], kap):
+            assert relmax(ctx.dfavg(), after["dfavg"]) <= TOL_GRAD * 4
+            assert relmax(ctx.A(), after["A"]) <= TOL_A
+            checked += 1
+    assert checked >= 5
+    st = tr.state()
+    ctx.set_state(st["t"], st["dfavg"], st["W"])                             # both continue from the oracle's state, freely
+    for _ in range(150):
+        tr.step()
+    ctx.steps(150)
+    assert ctx.counters()["nonconverged"] == 0
+    lo, rg, rank = ctx.validate()
+    lo_r, rg_r = tr.validate()
+    dim, f95, auc = ctx.stats()
+    dim_r, f95_r, auc_r = tr.stats()
+    assert abs(lo - lo_r) <= 0.05 * max(lo_r, 1e-6) + 1e-4 and abs(rg - rg_r) <= 0.05 * max(rg_r, 1e-6) + 1e-4
+    assert abs(rank - dim_r) <= max(2, dim_r // 20)
+    se = float(np.sqrt(max(f95_r * (1.0 - f95_r), 1e-6) / 250000))
+    assert abs(f95 - f95_r) <= max(1e-3, 3.0 * se) and abs(auc - auc_r) <= 3e-3
+    W = ctx.W()
+    d_all = ctx.project_sqdist(np.arange(N, dtype=np.int32), W)
+    f_o, a_o = ref.roc_stats(d_all, L)                                        # one model, both scorers: the +-0.1 % statement
+    assert f_o == f95 and abs(a_o - auc) <= 1e-12
+    print("500000 x 544: rank %d (oracle %d), FPR95 %.4f (%.4f), AUC %.5f (%.5f)" % (rank, dim_r, f95, f95_r, auc, auc_r))
+    ctx.close()
+    tr.close()
+
+
 @pytest.mark.parametrize("F,B", [(544, 200), (100, 33), (8, 4), (3, 2), (130, 16)])
 def test_operators_at_odd_widths(dlco, ref, F, B):
     """The single operators of the ABI at widths that are not tile multiples: every host-side array has the caller's

@@ -5,21 +5,26 @@
 #   3. the default bench line with its cpu_baseline leg
 # Outputs land in gpurun_out/profiles_new/; copy what is wanted into profiles/.
 set -e
-R=${DLCO_ROUND:-r3}
+R=${DLCO_ROUND:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 > $OUT/stats_bench.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --no-other-configs > $OUT/stats_bench.json 2> $OUT/stats.log
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 python3 $ROOT/tools/trace_breakdown.py $OUT/stats 200 $OUT/${R}_bench_kernel_stats_timed.csv > $OUT/${R}_bench_step_breakdown.txt
 rm -rf $OUT/stats
 # the same trace for the rank ~128 workload (BASELINE configs[2])
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $ROOT/bench.py --config c3 --no-cpu-baseline --reference-iters 0 > $OUT/stats_c3_bench.json 2> $OUT/stats_c3.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 $ROOT/bench.py --config c3 --no-cpu-baseline --reference-iters 0 --no-other-configs > $OUT/stats_c3_bench.json 2> $OUT/stats_c3.log
 python3 $ROOT/tools/trace_breakdown.py $OUT/stats_c3 200 $OUT/${R}_bench_c3_kernel_stats_timed.csv > $OUT/${R}_bench_c3_step_breakdown.txt
 rm -rf $OUT/stats_c3
+# the reference's own shape (500000 x 544): kernel names of the fused path at a width that is not a tile multiple
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ref544 -- python3 $ROOT/bench.py --config ref544 --no-cpu-baseline --reference-iters 0 > $OUT/stats_ref544_bench.json 2> $OUT/stats_ref544.log
+cp $OUT/stats_ref544/*/*_kernel_stats.csv $OUT/${R}_bench_ref544_kernel_stats.csv
+python3 $ROOT/tools/trace_breakdown.py $OUT/stats_ref544 200 $OUT/${R}_bench_ref544_kernel_stats_timed.csv > $OUT/${R}_bench_ref544_step_breakdown.txt
+rm -rf $OUT/stats_ref544
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --no-other-configs --steps 20 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
   DLCO_ROUND=$R python3 - $OUT/pmc_$c $c $OUT <<'PY'
 import csv, glob, sys
 d, c, out = sys.argv[1:4]
@@ -40,7 +45,7 @@ open("%s/pmc_mean_%s_split.txt" % (out, c), "w").write("%r %d\n" % (sum(float(r[
 print(c, "mean per launch:", mean, "over", len(rows))
 open("%s/pmc_mean_%s.txt" % (out, c), "w").write("%r %d\n" % (mean, len(rows)))
 # the tracker's product kernels on the packed dual average (two-way filter pass, three-way Rayleigh-Ritz pass)
-for tag, key in (("sym2", "skinny_sym_kernel<3, 2>"), ("sym3", "skinny_sym_kernel<3, 3>")):
+for tag, key in (("sym2", "skinny_sym_kernel<3, 2,"), ("sym3", "skinny_sym_kernel<3, 3,")):
     rs = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if key in r["Kernel_Name"] and r["Counter_Name"] == c][-40:]
     open("%s/pmc_mean_%s_%s.txt" % (out, c, tag), "w").write("%r %d\n" % (sum(rs) / max(len(rs), 1), len(rs)))
 PY
@@ -84,4 +89,6 @@ print(json.dumps(js))
 PY
 cd $ROOT && python3 bench.py > $OUT/${R}_bench_default.json 2> $OUT/bench_default.log
 python3 bench.py --config c3 --cpu-steps 2 > $OUT/${R}_bench_c3.json 2> $OUT/bench_c3.log
+python3 bench.py --config ref544 > $OUT/${R}_bench_ref544.json 2> $OUT/bench_ref544.log
+python3 bench.py --bf16 --no-cpu-baseline > $OUT/${R}_bench_bf16.json 2> $OUT/bench_bf16.log
 tail -c 600 $OUT/${R}_bench_default.json

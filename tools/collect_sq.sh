@@ -2,20 +2,20 @@
 # SQ counters (MFMA busy cycles, wave wait buckets) of the hot kernels, one --pmc pass:
 # run on the GPU box through gpurun from the repo root; writes gpurun_out/profiles_new/${R}_pmc_sq.{csv,json}
 set -e
-R=${DLCO_ROUND:-r3}
+R=${DLCO_ROUND:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
-  --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --steps 20 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.log
+  --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --no-cpu-baseline --reference-iters 0 --no-other-configs --steps 20 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.log
 DLCO_ROUND=$R python3 - $OUT/pmc_sq $OUT <<'PY'
 import csv, glob, json, os, sys, collections
 d, out = sys.argv[1:3]
 R = os.environ.get("DLCO_ROUND", "r3")
 f = glob.glob(d + "/*/*counter_collection.csv")[0]
 rows = list(csv.DictReader(open(f)))
-want = {"syrk_planes_kernel": "syrk_planes_kernel", "syrk_split_rows_kernel": "syrk_split_rows_kernel", "jacobi_mw_kernel": "jacobi_mw_kernel", "skinny_sym_kernel<3, 2>": "skinny_sym_kernel<3,2>", "skinny_sym_kernel<3, 3>": "skinny_sym_kernel<3,3>",
+want = {"syrk_planes_kernel": "syrk_planes_kernel", "syrk_split_rows_kernel": "syrk_split_rows_kernel", "jacobi_mw_kernel": "jacobi_mw_kernel", "skinny_sym_kernel<3, 2,": "skinny_sym_kernel<3,2>", "skinny_sym_kernel<3, 3,": "skinny_sym_kernel<3,3>",
         "jacobi_blk_kernel": "jacobi_blk_kernel", "chol_inv2_kernel": "chol_inv2_kernel", "project_rows_kernel": "project_rows_kernel"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
