@@ -209,6 +209,69 @@ def test_operators_at_odd_widths(dlco, ref, F, B):
     ctx.close()
 
 
+def test_width_beyond_the_packed_layout(dlco, ref):
+    """F = 8330 (66 tiles after padding to 8448: more than the 64 the packed layout takes): full F x F dual average, the
+    row-streaming product kernel with a K split that divides the tile count.  Gradient against float64, then three training
+    steps from W = 0 whose PSD projection is cheap to check exactly (the dual average has rank <= 3 * 2B = 48: A+ is computed
+    here in float64 from the eigen-decomposition of the matrix restricted to its range)."""
+    N, F, B = 600, 8330, 8
+    D, L = synth(N, F, k=16, seed=8330, sp=0.6, noise=0.15)
+    mu, gamma = 0.002, 0.5
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    assert ctx.device_width() == 8448
+    ctx.set_data(D, L)
+    rng = np.random.default_rng(1)
+    pr, nr = rng.integers(0, N, B).astype(np.int32), rng.integers(0, N, B).astype(np.int32)
+    rho, kap = rng.integers(0, 5, B).astype(np.int32), rng.integers(0, 5, B).astype(np.int32)
+    G1 = ctx.grad_rda(pr, nr, rho, kap, 0.37, 0.0, None)
+    P, Nn = D[pr].astype(np.float64), D[nr].astype(np.float64)
+    want = 0.37 * ((P * rho[:, None]).T @ P - (Nn * kap[:, None]).T @ Nn)
+    assert G1.shape == (F, F) and relmax(G1, want) <= TOL_GRAD * 4
+    del G1, want
+    for t in range(3):
+        ctx.step()
+        assert ctx.counters()["nonconverged"] == 0
+        G = ctx.dfavg().astype(np.float64)
+        # exact A+ = c (-G - mu I)_+ from the range of G: G = R^T S R with R = the (at most 2B (t+1)) rows that entered it
+        c = np.sqrt(t + 1.0) / gamma
+        Om = np.random.default_rng(t).standard_normal((F, 64))
+        R = np.linalg.qr(G @ Om)[0]                                        # an orthonormal basis of the range (rank <= 48)
+        w, Vs = np.linalg.eigh(-(R.T @ G @ R))
+        V = R @ Vs
+        keep = w > mu
+        Aplus = (V[:, keep] * (c * (w[keep] - mu))) @ V[:, keep].T
+        A = ctx.A().astype(np.float64)
+        assert np.abs(A - Aplus).max() <= TOL_A * np.abs(Aplus).max(), t
+        W = ctx.W()
+        assert W.shape == (int(keep.sum()), F) or abs(W.shape[0] - int(keep.sum())) <= 1
+    ctx.close()
+
+
+def test_device_resident_inputs_of_odd_width_and_shared_data(dlco):
+    """`dlco_set_data_device` with a matrix of the caller's row stride (544 floats: not a tile multiple, so the library copies
+    it into its padded layout) and `dlco_set_data_shared` (a second trainer on the first one's resident matrix) against
+    `dlco_set_data` from the host: bit-identical trainers."""
+    import torch
+    N, F, B = 6000, 544, 200
+    D, L = _data(N, F, seed=11)
+    a = dlco.Context(F, N, B=B, mu=0.001, gamma=0.1)
+    a.set_data(D, L)
+    t = torch.from_numpy(D).to("cuda")
+    torch.cuda.synchronize()
+    b = dlco.Context(F, N, B=B, mu=0.001, gamma=0.1)
+    b.set_data_device(t.data_ptr(), L)
+    c = dlco.Context(F, N, B=B, mu=0.001, gamma=0.1)
+    c.set_data_shared(a)
+    for ctx in (a, b, c):
+        ctx.steps(12)
+    Wa = a.W()
+    assert np.array_equal(Wa, b.W()) and np.array_equal(Wa, c.W())
+    assert np.array_equal(a.dfavg(), b.dfavg()) and np.array_equal(a.dfavg(), c.dfavg())
+    assert np.array_equal(b.get_rows(100, 5), D[100:105])
+    for ctx in (c, b, a):
+        ctx.close()
+
+
 def test_pj_learn_program_from_a_544_wide_gzip9_file(tmp_path):
     """The program a user of the reference runs (workspace/08-pjlearn.sh), on a file written like comp-uprjdists writes
     it ({128,1} chunks, gzip 9, src/comp-uprjdists.cpp:254,289-290) at the reference's own width."""
