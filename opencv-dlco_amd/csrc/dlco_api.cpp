@@ -61,7 +61,12 @@ struct dlco_ctx {
     DevBuf<int32_t> ids_all;
     IdView pos_rows, neg_rows, local_ids;
     const float *pd_cur = nullptr, *nd_cur = nullptr;    // distance vectors of the current step (see gather_dists)
-    DevBuf<int32_t> rho, kappa, act_ids, seed_ids;
+    DevBuf<int32_t> rho, kappa, act_ids, seed_ids, act_slot;
+    // the step's first filter term from its own rank update (kernels_rankupd.hip): the batch projection also covers the
+    // tracker's guard rows, and what the tracker needs of the step is handed over after the gradient
+    bool rank_update = false;
+    const float *ru_proj = nullptr;  // this step's projection [ru_rows][2 Bl] of the batch on the rows of W (guards included)
+    int ru_rows = 0;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
     DevBuf<char> pplane[3];          // split-bf16 planes of W for the fused many-row projection (kernels_project.hip)
     float *xdist = nullptr, *xgrad = nullptr;   // exchange buffers (own allocations unless bound by the caller)
@@ -268,10 +273,14 @@ void project_many(dlco_ctx *c, const int32_t *ids_dev, int row0, int n, const fl
 }
 
 // few rows (the training batch): split-K slabs summed in order, then squared
-void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, int r, float *out_dev)
+// r_ext > r: W holds r_ext rows, the tracker's guard rows behind its r own; all are projected (one GEMM), the distances
+// sum the first r, and the whole projection stays in place for the tracker (c->ru_proj)
+void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, int r, float *out_dev, int r_ext = 0)
 {
+    c->ru_proj = nullptr; c->ru_rows = 0;
     if (n <= 0) return;
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
+    const int rp = std::max(r, r_ext);
     if (c->cfg.grad_bf16 && r <= 96 && c->F % 64 == 0) {
         // BASELINE configs[4] variant: the batch projection on the bf16 matrix cores too (operands rounded to bf16 once,
         // fp32 accumulation), K split over enough slices to fill the chip, slices summed in order
@@ -289,23 +298,26 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
         c->prof.end(PROF_PROJECT);
         if (ok) return;
     }
-    const int bm = r <= 64 ? 64 : 128, bn = n <= 64 ? 64 : 128;
-    const long tiles = (long)((r + bm - 1) / bm) * ((n + bn - 1) / bn);
+    static const bool small_tiles = std::getenv("DLCO_PROJ_BIG_TILES") == nullptr;
+    const int bm = (rp <= 64 || (small_tiles && rp <= 128)) ? 64 : 128, bn = n <= 64 ? 64 : 128;
+    const long tiles = (long)((rp + bm - 1) / bm) * ((n + bn - 1) / bn);
     long split = std::max(1L, std::min((512 + tiles - 1) / tiles, (long)c->F / 128));
-    const size_t need = (size_t)(split + 1) * r * n;
-    if (need > c->proj_slab_floats) { c->proj_slab.alloc(need); c->proj_slab_floats = need; }
-    float *proj = c->proj_slab.p + (size_t)split * r * n;       // reduced [r][n] projection behind the slabs
+    const size_t need = (size_t)(split + 1) * rp * n;
+    if (need > c->proj_slab_floats) { sync(c); c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+    float *proj = c->proj_slab.p + (size_t)split * rp * n;      // reduced [rp][n] projection behind the slabs
     GemmArgs g;
-    g.M = r; g.N = n; g.K = c->F;
+    g.M = rp; g.N = n; g.K = c->F;
     g.A.p = Wd; g.A.ld = c->F; g.A.kmajor = false;
     const RowRef rr = rows_of(c, ids_dev, 0, n);
     g.B.p = c->dists; g.B.ld = c->F; g.B.kmajor = false; g.B.row_ids = rr.a; g.B.row_ids2 = rr.b;
     g.C = proj; g.ldc = n;
     g.split_k = (int)split; g.slab = c->proj_slab.p;
+    g.small_m_tiles = bm == 64;
     c->prof.begin(PROF_PROJECT);
     gemm_f32(g, c->stream);                                      // slabs summed in slice order: deterministic
     sqdist_from_proj(proj, 1, r, n, n, out_dev, c->stream);
     c->prof.end(PROF_PROJECT);
+    if (rp > r) { c->ru_proj = proj; c->ru_rows = rp; }
 }
 
 // dst = beta*dst_in + alpha * X^T diag(w) X over the active rows (upper triangle computed, mirrored)
@@ -386,7 +398,9 @@ void step_begin(dlco_ctx *c)
     // (letting the kernels read the pinned slot directly instead of this copy was measured slower: 0.852 against 0.838 ms per step)
     DLCO_HIP(hipMemcpyAsync(c->ids_all.p, slot, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     // P1+P2 on this rank's slots -> its slice of the exchange buffer
-    project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl);
+    // (the tracker's guard rows sit behind the r rows of W: projected along, see step_grad)
+    const int r_ext = (c->rank_update && c->r > 0 && c->eig->ext_rows() > c->r) ? c->eig->ext_rows() : 0;
+    project_few(c, c->local_ids.p, 2 * Bl, c->W.p, c->r, c->xdist + (size_t)c->cfg.rank * 2 * Bl, r_ext);
     c->phase = 1;
 }
 
@@ -398,11 +412,20 @@ void step_grad(dlco_ctx *c)
     (void)world;
     gather_dists(c, &c->pd_cur, &c->nd_cur);
     viol_counts_active_rows(c->pd_cur, c->nd_cur, B, c->rho.p, c->kappa.p, c->pos_rows.p, c->neg_rows.p, c->lo, c->lo + Bl,
-                            c->act_ids.p, c->act_w.p, c->k_active.p, c->stream);
+                            c->act_ids.p, c->act_w.p, c->k_active.p, c->stream, c->act_slot.p);
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
     if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed);
     else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->xgrad);
+    if (c->rank_update && c->ru_proj && c->syrk_planes.p) {
+        // dfAvg <- beta dfAvg + alpha X_a^T diag(w) X_a has just been applied: the tracker may form its first filter
+        // term from Y = Q H_t, the projections of the batch on its rows and the gradient's planes of X_a
+        RankUpdate ru;
+        ru.proj = c->ru_proj; ru.ldp = 2 * Bl; ru.rows = c->ru_rows;
+        ru.slot = c->act_slot.p; ru.w = c->act_w.p; ru.k_dev = c->k_active.p; ru.kmax = (2 * Bl + 31) & ~31;
+        ru.planes = c->syrk_planes.p; ru.alpha = alpha; ru.beta = beta;
+        c->eig->offer_rank_update(ru);
+    }
     c->phase = 2;
 }
 
@@ -593,7 +616,11 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         c->pos_rows.p = c->ids_all.p; c->neg_rows.p = c->ids_all.p + B; c->local_ids.p = c->ids_all.p + 2 * B;
         c->rho.alloc(B); c->kappa.alloc(B);
         const int kcap = (2 * B + 31) & ~31;                      // row lists are zero padded to whole K tiles
-        c->act_ids.alloc(kcap); c->act_w.alloc(kcap); c->seed_ids.alloc(kcap); c->seed_w.alloc(kcap);
+        c->act_ids.alloc(kcap); c->act_w.alloc(kcap); c->seed_ids.alloc(kcap); c->seed_w.alloc(kcap); c->act_slot.alloc(kcap);
+        // one rank, packed dual average, the gradient's default arithmetic (its split planes are what the shortcut reads)
+        c->rank_update = c->packed && cfg->world == 1 && syrk_planes_are_split3(cfg->grad_bf16 != 0) &&
+                         std::getenv("DLCO_NO_RANK_UPDATE") == nullptr;
+        c->eig->set_emit_guards(c->rank_update);
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;
         c->k_active.alloc(4);
@@ -1317,6 +1344,8 @@ int dlco_counters(const dlco_ctx *c, int64_t out[8])
     for (int i = 0; i < 8; i++) out[i] = 0;
     out[0] = c->steps_run; out[1] = c->active_rows_sum; out[2] = c->nonconv_steps;
     out[3] = c->eig->stats().jacobi_barrier_timeouts;
+    out[4] = c->eig->stats().rank_update_passes;
+    out[5] = (int64_t)(c->eig->stats().rank_update_check * 1e9);
     return DLCO_OK;
 }
 

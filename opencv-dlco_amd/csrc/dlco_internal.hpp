@@ -151,6 +151,7 @@ struct GemmArgs {
     int *split_out = nullptr;           // receives the number of K slices actually used
     const float *B2 = nullptr;          // twin product in the same launch: C2 = alpha * A * B2 (+ the same epilogue terms), B2 laid
     float *C2 = nullptr;                // out like B; needs split_k == 1
+    bool small_m_tiles = false;         // 64-row tiles whatever M (a 96-row operand: two short tiles run faster than one 128-row tile, measured)
 };
 
 void gemm_f32(const GemmArgs &a, hipStream_t s);
@@ -192,6 +193,17 @@ size_t syrk_planes_bytes(int kmax, int F);
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
                   int slab_cols = 0, bool bf16 = false, bool packed = false, void *planes_ws = nullptr);
+// true when syrk_rda_f32(bf16) writes the three-way split planes of syrk_split_rows_kernel into planes_ws (the default
+// arithmetic: not DLCO_SYRK_FP32, not the bf16-once variant): rank_first_term() reads operand 1 of them
+bool syrk_planes_are_split3(bool bf16);
+// The first Chebyshev term of a step's filter from the step's own rank update, without a pass over the matrix
+// (kernels_rankupd.hip): out = ay*Y + aq*Q + ac * C_w X_a, C_w[i][k] = w[k] * proj[row(i)][slot[k]] / wscale[i] with
+// row(i) = nw-1-i for i < nw (W's ascending order), i for the guard rows behind; X_a = operand 1 of `planes`; also emits
+// the two-way planes of `out` (split_x_kernel's order) when plane_hi/lo are given.  coeff_ws: rank_coeff_bytes(m, kmax).
+size_t rank_coeff_bytes(int m, int kmax);
+bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, float ay, float aq, float ac, float *out,
+                     const float *proj, long ldp, int nw, const float *wscale, const int32_t *slot, const float *w,
+                     const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s);
 size_t syrk_packed_floats(int F);
 void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s);      // upper tiles of a full matrix -> packed
 void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s);    // packed -> full symmetric matrix
@@ -221,7 +233,8 @@ void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float
 void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, hipStream_t s);
 // viol_counts + build_active_rows in one launch
 void viol_counts_active_rows(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
-                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s);
+                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s,
+                             int32_t *slots = nullptr);   // slots[k]: position of active row k in the rank's [pos | neg] slot list
 // build the stacked weighted row list of the SYRK: ids[2B] = (pos rows, neg rows), w[2B] = (rho, -kappa);
 // rows with zero weight are dropped; *k_active receives the count. [lo,hi) selects the slots owned by a rank.
 void build_active_rows(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho, const int32_t *kappa,
@@ -236,8 +249,10 @@ void scale_rows(float *dst, long ldd, const float *src, long lds, const float *s
 // out_a[i] = pa[ids ? ids[i] : base + i], out_b likewise: row ids -> (patch, patch) ids of the pair table
 // W[j][:] = sqrt(cscale * (theta[nw-1-j] - mu)) * Q[nw-1-j][:] for j < nw: the kept Ritz pairs in ascending
 // eigenvalue order, scaled like the reference's W = sqrt(e) * v^T (src/pj-learn.cpp:480-487)
+// m_ext > nw: the rows nw..m_ext-1 of Q (the guard rows) are copied unscaled behind the nw rows of W, and wscale[i]
+// receives the factor row i of Q went out with (1 for guards) - what the next step's rank update divides by
 void emit_w_rows(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu, float cscale, int F,
-                 hipStream_t s);
+                 hipStream_t s, int m_ext = 0, float *wscale = nullptr);
 void translate_ids(const int32_t *ids, int base, int n, const int32_t *pa, const int32_t *pb, int32_t *out_a, int32_t *out_b,
                    hipStream_t s);
 void fill_f32(float *p, float v, size_t n, hipStream_t s);

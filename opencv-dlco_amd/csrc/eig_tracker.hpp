@@ -22,6 +22,22 @@ namespace dlco {
 struct EigStats {
     int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0, cheap_passes = 0;
     int64_t jacobi_barrier_timeouts = 0;   // multi-workgroup Jacobi calls that gave up at their grid barrier and were redone on one workgroup
+    int64_t rank_update_passes = 0;        // first filter terms formed from the step's rank update instead of a pass over the matrix
+    double rank_update_check = 0.0;        // DLCO_RANK_UPDATE_CHECK=1: largest |shortcut - product| / max|product| seen (developer aid)
+};
+
+// What the trainer knows about the matrix of the NEXT update(): G = beta * G_prev + alpha * X_a^T diag(w) X_a, G_prev the
+// matrix of the last update(), X_a the active rows of the step (kernels_rankupd.hip).
+struct RankUpdate {
+    const float *proj = nullptr;     // [rows][ldp]: projections of the batch slots on the rows of W as the last update() emitted them (guard rows included)
+    long ldp = 0;
+    int rows = 0;
+    const int32_t *slot = nullptr;   // slot[k]: column of proj that belongs to active row k
+    const float *w = nullptr;        // weights of the active rows
+    const int *k_dev = nullptr;      // their count (device)
+    int kmax = 0;                    // capacity of the lists (multiple of 32, zero padded)
+    const void *planes = nullptr;    // syrk_split_rows_kernel's planes of the active rows
+    float alpha = 0.f, beta = 1.f;
 };
 
 class EigTracker {
@@ -57,6 +73,12 @@ public:
     // trainer passes rows of the step's batch: the directions that enter the dual average come from their span.
     void set_growth_rows(std::function<int(float *dst, int want)> cb) { grow_cb_ = std::move(cb); }
     int readback_extra() const { return extra_val_; }
+    // update() also writes the block's guard rows behind the nw rows of W (the caller's W holds block_rows() rows then) and
+    // keeps the scale of every row: the step's own projection of its batch on these rows is what offer_rank_update() hands back
+    void set_emit_guards(bool on) { emit_guards_ = on; }
+    int ext_rows() const { return wext_rows_; }          // rows of W the last update() wrote, guard rows included (0: none)
+    // consumed by the next update() only; ignored when the block is not the one the projection was made with
+    void offer_rank_update(const RankUpdate &ru) { ru_ = ru; ru_offered_ = true; }
     void set_packed(bool on) { packed_ = on; }
     bool packed() const { return packed_; }
     static bool packed_supported(int F) { return F % 128 == 0 && F / 128 <= 64 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }
@@ -83,6 +105,13 @@ private:
     const int *extra_dev_ = nullptr;
     int extra_val_ = 0;
     bool packed_ = false;
+    bool emit_guards_ = false;
+    int wext_rows_ = 0, wext_nw_ = 0;   // W as the last update() left it: rows in all, Ritz rows among them
+    RankUpdate ru_;
+    bool ru_offered_ = false;
+    bool ru_check_ = std::getenv("DLCO_RANK_UPDATE_CHECK") != nullptr;
+    DevBuf<float> wscale_;
+    DevBuf<char> coeff_;
     const float *chain_planes_of_ = nullptr;   // the matrix whose two-way planes sit in plane_hi_/plane_lo_ (emitted by a reduction)
     int chain_rows_ = 0;
     bool chain_next_ = false;        // the product being issued feeds the next one of a filter chain
@@ -100,6 +129,7 @@ private:
     int last_deg_ = 0;               // degree actually used by the last filter (after the amplification cap)
     bool y_ok_ = false;              // Y_ = Q_ * H row for row for the matrix of the current update
     bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
+    float tol_pass2_ = std::getenv("DLCO_EIG_TOL_PASS2") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS2")) : 0.5f;   // see update(): tolerance factor of the passes after the first
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
     bool guard_stop_ = std::getenv("DLCO_JACOBI_ALL_PAIRS") == nullptr;       // see update(): guard-guard pairs do not prolong Jacobi

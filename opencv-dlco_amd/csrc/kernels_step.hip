@@ -3,6 +3,8 @@
 // (cbalint13/opencv-dlco).
 #include "dlco_internal.hpp"
 
+#include <algorithm>
+
 namespace dlco {
 
 namespace {
@@ -102,7 +104,8 @@ __global__ void viol_kernel(const float *pd, const float *nd, int B, int32_t *rh
 
 // stacked, weighted, compacted row list of the gradient SYRK (slots [lo,hi) of each class)
 __device__ __forceinline__ void active_rows_body(const int32_t *pos_rows, const int32_t *neg_rows, const int32_t *rho,
-                                                 const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active)
+                                                 const int32_t *kappa, int B, int lo, int hi, int32_t *ids, float *w, int *k_active,
+                                                 int32_t *slots = nullptr)
 {
     // ordered stream compaction of the 2*(hi-lo) candidates (positives first) by one workgroup:
     // chunk-wise ballot + prefix over the waves keeps the output order equal to the slot order
@@ -130,6 +133,7 @@ __device__ __forceinline__ void active_rows_body(const int32_t *pos_rows, const 
             const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
             ids[pos] = id;
             w[pos] = wt;
+            if (slots) slots[pos] = e;
         }
         __syncthreads();
         if (tid == 0) { int s = 0; for (int v = 0; v < nw; v++) s += wave_cnt[v]; base += s; }
@@ -147,13 +151,13 @@ __global__ void active_rows_kernel(const int32_t *pos_rows, const int32_t *neg_r
 }
 // V1 and the row list in one launch (the step's own sequence: one workgroup does both anyway)
 __global__ void viol_active_kernel(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
-                                   const int32_t *neg_rows, int lo, int hi, int32_t *ids, float *w, int *k_active)
+                                   const int32_t *neg_rows, int lo, int hi, int32_t *ids, float *w, int *k_active, int32_t *slots)
 {
     extern __shared__ float sh[];
     viol_body(sh, pd, nd, B, rho, kappa);
     __threadfence_block();
     __syncthreads();
-    active_rows_body(pos_rows, neg_rows, rho, kappa, B, lo, hi, ids, w, k_active);
+    active_rows_body(pos_rows, neg_rows, rho, kappa, B, lo, hi, ids, w, k_active, slots);
 }
 
 // H1 (src/kernelop-opencv.cu:49-66): one thread per positive row, the inner sum runs over the
@@ -236,12 +240,13 @@ __global__ void scale_rows_kernel(float *dst, long ldd, const float *src, long l
 }
 
 __global__ void emit_w_kernel(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu,
-                              float cscale, int F)
+                              float cscale, int F, int m_ext, float *wscale)
 {
     const int j = blockIdx.x;
-    if (j >= nw) return;
-    const int i = nw - 1 - j;
-    const float sc = sqrtf(cscale * (theta[i] - mu));
+    if (j >= max(nw, m_ext)) return;
+    const int i = j < nw ? nw - 1 - j : j;                              // guard rows keep their place behind the nw rows of W
+    const float sc = j < nw ? sqrtf(cscale * (theta[i] - mu)) : 1.0f;
+    if (wscale && threadIdx.x == 0) wscale[i] = sc;
     for (int c = threadIdx.x * 4; c < F; c += blockDim.x * 4) {
         float4 v = *reinterpret_cast<const float4 *>(Q + (long)i * ldq + c);
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
@@ -338,12 +343,13 @@ void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t 
 }
 
 void viol_counts_active_rows(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, const int32_t *pos_rows,
-                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s)
+                             const int32_t *neg_rows, int slot_lo, int slot_hi, int32_t *ids, float *w, int *k_active, hipStream_t s,
+                             int32_t *slots)
 {
     if (B <= 0) return;
     DLCO_CHECK(B <= 8192, -2, "viol_counts: batch too large for one workgroup's LDS");
     hipLaunchKernelGGL(viol_active_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), s, pd, nd, B, rho, kappa, pos_rows, neg_rows, slot_lo,
-                       slot_hi, ids, w, k_active);
+                       slot_hi, ids, w, k_active, slots);
     DLCO_HIP(hipGetLastError());
 }
 
@@ -418,10 +424,11 @@ void unpack_cols(float *dst, long ld, const float *src, int cw, int rows, int wo
 }
 
 void emit_w_rows(float *W, long ldw, const float *Q, long ldq, const float *theta, int nw, float mu, float cscale, int F,
-                 hipStream_t s)
+                 hipStream_t s, int m_ext, float *wscale)
 {
-    if (nw <= 0) return;
-    hipLaunchKernelGGL(emit_w_kernel, dim3(nw), dim3(256), 0, s, W, ldw, Q, ldq, theta, nw, mu, cscale, F);
+    const int rows = std::max(nw, m_ext);
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(emit_w_kernel, dim3(rows), dim3(256), 0, s, W, ldw, Q, ldq, theta, nw, mu, cscale, F, m_ext, wscale);
     DLCO_HIP(hipGetLastError());
 }
 

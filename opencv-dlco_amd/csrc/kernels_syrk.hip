@@ -623,6 +623,8 @@ static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count
 }
 
 
+bool syrk_planes_are_split3(bool bf16) { return !bf16 && std::getenv("DLCO_SYRK_FP32") == nullptr; }
+
 size_t syrk_planes_bytes(int kmax, int F) { return (size_t)2 * (kmax / PL_KD) * (F / TB) * PL_IMG; }
 
 // Workspace of the split planes for callers that bring none: one per device, grown on demand (2 operands x 6 bytes per staged value).

@@ -82,7 +82,37 @@ def _child(case):
         tr.close()
         return worst
 
-    if case == "syrk_fp32":
+    def free_run(F, nstep, expect_passes):
+        N, B, mu, gamma = 4000, 200, 0.004, 0.5
+        D, L = synth(N, F, k=20, seed=9)
+        ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+        ctx.set_data(D, L)
+        worst = 0.0
+        for s in range(nstep):
+            ctx.step()
+            Ap, _, _ = ref.psd_project(ref.dual_to_primal(ctx.dfavg(), mu, gamma, s))
+            e = relmax(ctx.A(), Ap)
+            worst = max(worst, e)
+            assert e <= TOL_A, (s, e)
+        cn = ctx.counters()
+        assert cn["nonconverged"] == 0
+        if expect_passes:
+            assert cn["rank_update_passes"] >= nstep - 8, cn
+        else:
+            assert cn["rank_update_passes"] == 0, cn
+        ctx.close()
+        return worst, cn
+
+    if case == "rank_update_check":
+        # the shortcut term beside the product it replaces, every step (DLCO_RANK_UPDATE_CHECK): the product is a
+        # two-way split one (~1e-5 of its largest entry), the shortcut is the more exact of the two
+        worst, cn = free_run(256, 30, True)
+        print("free run with the check: A+ %.2e, largest deviation of a first term %.2e" % (worst, cn["rank_update_check"]))
+        assert 0.0 < cn["rank_update_check"] <= 1e-4, cn
+    elif case == "no_rank_update":
+        worst, cn = free_run(256, 30, False)
+        print("free run without the shortcut: A+ %.2e" % worst)
+    elif case == "syrk_fp32":
         for F, B, z in ((128, 8, 0.0), (256, 200, 0.3), (384, 33, 0.9), (544, 200, 0.2)):
             print("grad_rda F=%d B=%d: %.2e" % (F, B, grad_case(F, B, z)))
         print("teacher forced: %.2e" % teacher_forced(256, 200, 8))
@@ -102,6 +132,8 @@ CASES = {
     "fp32_products": {"DLCO_FP32_FILTER": "1", "DLCO_FP32_RR": "1"},
     "no_packed": {"DLCO_NO_PACKED": "1"},
     "jmw_timeout": {"DLCO_TEST_JMW_TIMEOUT": "1"},
+    "rank_update_check": {"DLCO_RANK_UPDATE_CHECK": "1"},
+    "no_rank_update": {"DLCO_NO_RANK_UPDATE": "1"},
 }
 
 

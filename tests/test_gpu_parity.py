@@ -356,6 +356,28 @@ def test_teacher_forced_live(dlco, ref):
     tr.close()
 
 
+@pytest.mark.parametrize("F,mu", [(256, 0.004), (544, 0.002)])
+def test_free_run_each_step_against_ssyevr(dlco, ref, F, mu):
+    """A live chain of steps (no state hand-over: the tracker carries its block, and its first filter term comes from the
+    step's own rank update, kernels_rankupd.hip): after every step the GPU's A+ is compared with the oracle's ssyevr
+    projection of the GPU's OWN dual average (src/pj-learn.cpp:434-490)."""
+    N, B, gamma = 4000, 200, 0.5
+    D, L = synth(N, F, k=20, seed=9)
+    ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+    ctx.set_data(D, L)
+    nstep = 40
+    for s in range(nstep):
+        ctx.step()
+        A = ref.dual_to_primal(ctx.dfavg(), mu, gamma, s)
+        Ap, _, _ = ref.psd_project(A)
+        _check_A("free run F=%d step by step" % F, ctx.A(), Ap)
+    cn = ctx.counters()
+    assert cn["nonconverged"] == 0
+    # every step but the first few (block still growing, no Ritz block to carry) takes the shortcut
+    assert cn["rank_update_passes"] >= nstep - 8, cn
+    ctx.close()
+
+
 def test_validation_and_stats(dlco, ref):
     N, F, B = 6000, 64, 50
     D, L = synth(N, F, k=10, seed=21, sp=0.7, noise=0.2)
