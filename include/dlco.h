@@ -297,7 +297,8 @@ int dlco_profile_read(dlco_ctx *ctx, const char *kernel, int64_t *launches, doub
  * workgroup: a slow event, never a wrong result), out[4] = tracker updates whose first filter term came from the
  * step's own rank update (dfAvg_{t+1} = beta dfAvg_t + alpha X_a^T diag(w) X_a, src/pj-learn.cpp:367-422) instead
  * of a pass over the dual average, out[5] = with DLCO_RANK_UPDATE_CHECK=1 in the environment, 1e9 x the largest
- * relative deviation of such a term from the product it replaces (developer aid), out[6..7] reserved. */
+ * relative deviation of such a term from the product it replaces (developer aid), out[6] = tracker passes that ran
+ * with the converged top of the block locked out of the filter (start-up transient), out[7] = rows locked in them. */
 int dlco_counters(const dlco_ctx *ctx, int64_t out[8]);
 /* Tracker statistics since creation: filter/RR iterations, H-products (in rows), restarts. */
 int dlco_eig_stats(const dlco_ctx *ctx, int64_t *iters, int64_t *product_rows, int64_t *jacobi_sweeps,

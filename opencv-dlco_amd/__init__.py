@@ -448,7 +448,7 @@ class Context:
         out = (C.c_int64 * 8)()
         self._ck(self.L.dlco_counters(self.h, out))
         return dict(steps=out[0], active_rows=out[1], nonconverged=out[2], jacobi_barrier_timeouts=out[3],
-                    rank_update_passes=out[4], rank_update_check=out[5] * 1e-9)
+                    rank_update_passes=out[4], rank_update_check=out[5] * 1e-9, locked_passes=out[6], locked_rows=out[7])
 
     def eig_stats(self):
         a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()

@@ -1346,6 +1346,8 @@ int dlco_counters(const dlco_ctx *c, int64_t out[8])
     out[3] = c->eig->stats().jacobi_barrier_timeouts;
     out[4] = c->eig->stats().rank_update_passes;
     out[5] = (int64_t)(c->eig->stats().rank_update_check * 1e9);
+    out[6] = c->eig->stats().locked_passes;
+    out[7] = c->eig->stats().locked_rows;
     return DLCO_OK;
 }
 

@@ -282,16 +282,18 @@ void EigTracker::project_out(float *Wp, int np, const float *Q, int kept)
 // value, i.e. by how strongly the filter amplified them; the caller cuts the panels so that
 // rows of different provenance or of very different amplification never share one.  Nothing
 // here synchronises with the host and no row is dropped (dependent rows become zero rows).
-int EigTracker::orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends)
+int EigTracker::orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends, int skip)
 {
     // One panel (the steady state): Cholesky QR is invariant under a scaling of the rows - the Gram entries keep their
     // relative accuracy, the dead-row rule compares a pivot with the row's own diagonal entry - so the rows go in as the
     // filter left them.  With several panels the rows are normalised first: the Gram-Schmidt step between panels zeroes
     // what is left of a row after projection against a threshold that assumes unit rows.
-    const bool one_panel = rows <= CHOL_INV_MAX_N && (panel_ends.empty() || panel_ends[0] >= rows);
-    if (!one_panel) row_normalize(Z, F_, rows, F_, s_);
+    const bool one_panel = skip == 0 && rows <= CHOL_INV_MAX_N && (panel_ends.empty() || panel_ends[0] >= rows);
+    if (!one_panel) row_normalize(Z + (size_t)skip * F_, F_, rows - skip, F_, s_);
     size_t pi = 0;
-    for (int p0 = 0; p0 < rows;) {
+    // (the first `skip` rows are orthonormal as they are - locked Ritz vectors - and only serve as the span the panels
+    // behind them are projected against)
+    for (int p0 = skip; p0 < rows;) {
         while (pi < panel_ends.size() && panel_ends[pi] <= p0) pi++;
         int pend = pi < panel_ends.size() ? std::min(rows, panel_ends[pi]) : rows;
         if (pend - p0 > CHOL_INV_MAX_N) pend = p0 + CHOL_INV_MAX_N;
@@ -417,6 +419,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     for (; it < max_iter_; it++) {
         float *Z = Q_;
         panel_ends.clear();
+        int lock_rows = 0;
         // The filter is only applied to a block of Ritz vectors (theta known): the amplification of
         // each row is then predictable and the panels of the orthonormalisation can follow it.
         if (m_ < live_ && n_ritz > 0) {
@@ -431,19 +434,64 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             // keep the top/guard amplification ratio T_d(xmax) below ~1e5: the guard rows survive the
             // cancellation against the amplified rows with ~1e5 * 6e-8 relative noise
             const int dcap = (int)(12.2f / std::acosh(xmax));
-            d = std::max(2, std::min(d, dcap));
+            // ---- locking (passes after the first): while theta_top / mu is in the hundreds (the start-up transient) the
+            // cap above holds the filter at degree 2-4, and the pairs just above mu - hundreds of them, a dense spectrum -
+            // gain a factor ~1.6 per pass: ten passes per step.  The pairs at the top converge in the first pass or two
+            // (their amplification is the largest).  Once they have - residuals of the CURRENT matrix, a quarter of the
+            // tolerance - they are locked: not filtered, and projected out of every term of the recurrence that runs on
+            // the rows below them, so that the cap is set by the largest UNLOCKED Ritz value and the degree can rise.
+            // (The locked rows stay in the Rayleigh-Ritz step and in the convergence test.)
+            int n_lock = 0, dcap_a = dcap;
+            if (lock_ && it >= 1 && n_ritz == m_ && nw > 0 && m_ > 32 && dcap < d + 4) {
+                const float emax_l = cscale * (h_theta_[0] - mu);
+                int np = 0;
+                while (np < nw && np < m_ - 16 && cscale * h_res_[np] <= 0.25f * tol * emax_l) np++;
+                if (np >= 8) {
+                    const float xa = std::max(1.5f, (std::max(h_theta_[np], mu) - c0) / e0);
+                    const int cap_a = (int)(12.2f / std::acosh(xa));
+                    if (cap_a >= dcap + 2) { n_lock = np; dcap_a = cap_a; }
+                }
+            }
+            if (n_lock > 0) d = std::min(16, d + 4);
+            d = std::max(2, std::min(d, dcap_a));
             // A pass that missed the tolerance only narrowly is followed by a degree-1 pass that costs
             // no product at all: Y = Q H is still there from the Rayleigh-Ritz step, and
             // (H - c0) Q / e0 = (Y - c0 Q) / e0 already damps everything below the block by the
             // factor the marginal case needs.
-            const bool cheap = it >= 1 && !cheap_done && y_ok_ && cheap_pass_ && last_crit_ <= 4.0f * tol;
+            // (It gains a factor 0.5-0.9 on the criterion, measured, and what it must reach is the tolerance of the passes
+            // after the first: only a miss within 1.6x of THAT is worth a pass without products.)
+            const bool cheap = it >= 1 && !cheap_done && y_ok_ && cheap_pass_ && last_crit_ <= cheap_margin_ * tol_pass2_ * tol;
             if (cheap) {
                 cheap_done = true;                                   // once per step: if it is not enough, filter properly
                 d = 1;
+                n_lock = 0;
                 axpby_inplace(Y_, Q_, 1.0f / e0, -c0 / e0, (size_t)m_ * F_, s_);
                 Z = Y_;
                 y_ok_ = false;
                 st_.cheap_passes++;
+            } else if (n_lock > 0) {
+                // the recurrence on the rows below the locked ones, every term cleaned of the locked span (its top
+                // components would otherwise grow by ~2 x_top per product against ~2 x_j for the rows' own); no carried
+                // planes here: the projection changes a term after its product's reduction has split it
+                const int na = m_ - n_lock;
+                const size_t off = (size_t)n_lock * F_;
+                y_ok_ = false;
+                const float *prev = Q_;
+                float *cur = pick({Q_, Y_});
+                chain_planes_of_ = nullptr;
+                chain_next_ = false;
+                product(Q_ + off, na, G, -1.0f / e0, cur + off, Q_ + off, -c0 / e0, nullptr, 0.f, true);
+                project_out(cur + off, na, Q_, n_lock);
+                for (int k = 2; k <= d; k++) {
+                    float *nxt = pick({Q_, prev, cur});
+                    product(cur + off, na, G, -2.0f / e0, nxt + off, cur + off, -2.0f * c0 / e0, prev + off, -1.0f, true);
+                    project_out(nxt + off, na, Q_, n_lock);
+                    prev = cur; cur = nxt;
+                }
+                DLCO_HIP(hipMemcpyAsync(cur, Q_, off * sizeof(float), hipMemcpyDeviceToDevice, s_));
+                Z = cur;
+                st_.locked_passes++;
+                st_.locked_rows += n_lock;
             } else {
                 const float *prev = Q_;
                 float *cur = pick({Q_, Y_});
@@ -499,9 +547,11 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             // panel.  A Ritz row carries the directions above it only at the level of its own
             // residual, so after the filter it is at worst (residual level x amplification ratio)
             // parallel to them: CholQR2 resolves that as long as the product stays below ~1e2.
-            int start = 0;
+            int start = n_lock;
             double amp0 = 0.0;
-            for (int j = 0; j < n_ritz; j++) {
+            if (n_lock > 0) panel_ends.push_back(n_lock);
+            lock_rows = n_lock;
+            for (int j = n_lock; j < n_ritz; j++) {
                 const double x = std::max(1.0, (double)(h_theta_[j] - c0) / e0);
                 const double amp = std::cosh((double)d * std::acosh(x));
                 if (j == start) amp0 = amp;
@@ -513,7 +563,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         panel_ends.push_back(m_);
         // ---- orthonormalise, Rayleigh-Ritz -------------------------------------------------------
         float *Qo = Z;
-        orthonormalize(Z, m_, pick({Z}), panel_ends);                // in place
+        orthonormalize(Z, m_, pick({Z}), panel_ends, lock_rows);     // in place
         float *Yb = pick({Qo});
         product(Qo, m_, G, -1.0f, Yb, nullptr, 0.f, nullptr, 0.f, false);     // Yb = Qo * H, exact fp32
         gram(Yb, Qo, m_, Tm_.p);
@@ -625,8 +675,8 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         // the 1e-4 gate at eig_tol = 2e-4).  Passes after the first therefore converge to half of it.
         else conv = crit <= (it == 0 ? tol : tol_pass2_ * tol) * emax && guards_ok;
         if (debug_)
-            std::fprintf(stderr, "[eig] upd %ld it %d deg %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g guards_ok %d conv %d\n",
-                         (long)st_.updates, it, last_deg_, m_, nw, h_theta_[0], h_theta_[m_ - 1], mu, lo_bound_, last_crit_,
+            std::fprintf(stderr, "[eig] upd %ld it %d deg %d lock %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g guards_ok %d conv %d\n",
+                         (long)st_.updates, it, last_deg_, lock_rows, m_, nw, h_theta_[0], h_theta_[m_ - 1], mu, lo_bound_, last_crit_,
                          (int)guards_ok, (int)conv);
         if (h_theta_[m_ - 1] < lo_bound_) lo_bound_ = h_theta_[m_ - 1] - 0.5f * std::fabs(h_theta_[m_ - 1]) - 1e-12f;
         // ---- grow the block when the positive eigenspace reaches into the guard ------------------

@@ -22,6 +22,7 @@ namespace dlco {
 struct EigStats {
     int64_t iters = 0, product_rows = 0, jacobi_sweeps = 0, updates = 0, nonconverged = 0, cheap_passes = 0;
     int64_t jacobi_barrier_timeouts = 0;   // multi-workgroup Jacobi calls that gave up at their grid barrier and were redone on one workgroup
+    int64_t locked_passes = 0, locked_rows = 0;   // filter passes that ran with the converged top of the block locked, rows locked in them
     int64_t rank_update_passes = 0;        // first filter terms formed from the step's rank update instead of a pass over the matrix
     double rank_update_check = 0.0;        // DLCO_RANK_UPDATE_CHECK=1: largest |shortcut - product| / max|product| seen (developer aid)
 };
@@ -92,7 +93,7 @@ private:
     void gram_rect(const float *X, int xrows, const float *Y, int yrows, float *T);
     void project_out(float *Wp, int np, const float *Q, int kept);
     void rotate(const float *C, long ldc, int k_in, int k_out, const float *X, float *out, const float *X2 = nullptr, float *out2 = nullptr);
-    int orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends);
+    int orthonormalize(float *Z, int rows, float *scratch, const std::vector<int> &panel_ends, int skip = 0);
     int drop_dead_rows();
     void refresh_lower_bound(const float *G, int iters, float theta_top);
     void append_random(float *Q, int have, int add);
@@ -129,6 +130,8 @@ private:
     int last_deg_ = 0;               // degree actually used by the last filter (after the amplification cap)
     bool y_ok_ = false;              // Y_ = Q_ * H row for row for the matrix of the current update
     bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
+    float cheap_margin_ = std::getenv("DLCO_CHEAP_MARGIN") ? (float)std::atof(std::getenv("DLCO_CHEAP_MARGIN")) : 1.6f;
+    bool lock_ = std::getenv("DLCO_NO_LOCKING") == nullptr;           // see update(): converged top pairs leave the filter
     float tol_pass2_ = std::getenv("DLCO_EIG_TOL_PASS2") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS2")) : 0.5f;   // see update(): tolerance factor of the passes after the first
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;

@@ -22,6 +22,6 @@ for s in range(nstep):
     Ap, W, _ = ref.psd_project(ref.dual_to_primal(ctx.dfavg(), mu, gamma, s))
     e = relmax(ctx.A(), Ap)
     st, cn = ctx.eig_stats(), ctx.counters()
-    print("step %2d rank %3d/%3d err %.2e passes %d rows %d block %d ru %d chk %.2e" % (s, ctx.W().shape[0], W.shape[0], e, st["iters"] - prev["iters"],
-          st["product_rows"] - prev["product_rows"], st["block_rows"], cn["rank_update_passes"], cn["rank_update_check"]))
+    print("step %2d rank %3d/%3d err %.2e passes %d rows %d block %d ru %d chk %.2e locked %d/%d" % (s, ctx.W().shape[0], W.shape[0], e, st["iters"] - prev["iters"],
+          st["product_rows"] - prev["product_rows"], st["block_rows"], cn["rank_update_passes"], cn["rank_update_check"], cn["locked_passes"], cn["locked_rows"]))
     prev = st
