@@ -552,8 +552,8 @@ def main():
     n_syrk, ms_syrk = ctx.profile_read("grad_syrk")
     ctx.profile_enable(0)
     bsteps = 0 if args.no_profile else max(1, min(args.steps, 100))
-    n_prod = n_jac = n_prj = 0
-    ms_prod = ms_jac = ms_prj = 0.0
+    n_prod = n_jac = n_prj = n_ru = 0
+    ms_prod = ms_jac = ms_prj = ms_ru = 0.0
     if bsteps:
         ctx.profile_enable(1)
         R.run(bsteps)
@@ -561,6 +561,7 @@ def main():
         n_prod, ms_prod = ctx.profile_read("eig_product")
         n_jac, ms_jac = ctx.profile_read("jacobi")
         n_prj, ms_prj = ctx.profile_read("project")
+        n_ru, ms_ru = ctx.profile_read("rank_update")
         ctx.profile_enable(0)
     bdiv = max(bsteps, 1)
 
@@ -689,16 +690,25 @@ def main():
              "work_per_launch": dfavg_bytes, "work_unit": "bytes of the dual average one pass must read",
              "achieved": (dfavg_bytes / t_prod / 1e9) if n_prod else None, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
              "frac": (dfavg_bytes / t_prod / 1e12 / PEAK_HBM_TBS) if n_prod else None},
+            # the step's first filter term from its own rank update (kernels_rankupd.hip): in place of one pass over dfAvg it
+            # reads the x planes of the active rows, Y and Q of the block, and writes the term and its two-way planes
+            {"group": "eig_rank_update", "bound": "latency / L2 (two short launches: coefficient fragments, then 256 workgroups of a few hundred MFMAs)",
+             "ms_per_step": ms_ru / bdiv, "launches_per_step": n_ru / bdiv,
+             "work_per_launch": 6.0 * k_mean * Fd + 4.0 * 4.0 * es1["block_rows"] * Fd, "work_unit": "bytes (x planes in, Y and Q in, term and planes out)",
+             "achieved": ((6.0 * k_mean * Fd + 16.0 * es1["block_rows"] * Fd) / (ms_ru / n_ru * 1e-3) / 1e9) if n_ru else None,
+             "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+             "frac": ((6.0 * k_mean * Fd + 16.0 * es1["block_rows"] * Fd) / (ms_ru / n_ru * 1e-3) / 1e12 / PEAK_HBM_TBS) if n_ru else None},
             {"group": "eig_jacobi", "bound": "latency (m x m problem on one workgroup; a chain of dependent rotation rounds)",
              "ms_per_step": ms_jac / bdiv, "launches_per_step": n_jac / bdiv, "frac": None},
             {"group": "project", "bound": "latency (2B gathered rows x F x 4 bytes = %d per step)" % int(8 * B * Fd / world),
              "ms_per_step": ms_prj / bdiv, "launches_per_step": n_prj / bdiv, "frac": None},
             {"group": "other", "bound": "orthonormalisation (Gram, L^-1, L^-1 Z), rotation GEMMs, reductions, violation counts, launch gaps",
-             "ms_per_step": dt / args.steps * 1e3 - ms_syrk / args.steps - (ms_prod + ms_jac + ms_prj) / bdiv, "frac": None},
+             "ms_per_step": dt / args.steps * 1e3 - ms_syrk / args.steps - (ms_prod + ms_jac + ms_prj + ms_ru) / bdiv, "frac": None},
         ],
         "breakdown_ms_per_step": {
             "grad_syrk": ms_syrk / args.steps,
             "eig_products": ms_prod / bdiv,
+            "eig_rank_update": ms_ru / bdiv,
             "eig_jacobi": ms_jac / bdiv,
             "project": ms_prj / bdiv,
             "note": "grad_syrk: HIP events inside the timed region; the other groups: over the %d steps that follow it" % bsteps,
@@ -706,6 +716,8 @@ def main():
             "eig_jacobi_sweeps_per_step": (es1["jacobi_sweeps"] - es0["jacobi_sweeps"]) / args.steps,
             "eig_product_rows_per_step": (es1["product_rows"] - es0["product_rows"]) / args.steps,
             "eig_block_rows": es1["block_rows"],
+            "eig_rank_update_passes_per_step": (cn1["rank_update_passes"] - cn0["rank_update_passes"]) / args.steps,
+            "eig_locked_passes_per_step": (cn1["locked_passes"] - cn0["locked_passes"]) / args.steps,
         },
     }
     # ---- N > 1: the other two modes SURVEY 8(d)/(e) and BASELINE configs[3] name, measured after the headline

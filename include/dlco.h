@@ -285,7 +285,7 @@ int dlco_log_step(dlco_ctx *ctx, dlco_log_entry *out);
 int dlco_get_saved(dlco_ctx *ctx, float *W_host, int32_t *r, float *A_host);
 
 /* ---- measurement ------------------------------------------------------------------------ */
-/* on = 1: the launches of the kernel groups "grad_syrk", "eig_product", "jacobi", "project" are bracketed by HIP events on
+/* on = 1: the launches of the kernel groups "grad_syrk", "eig_product", "jacobi", "project", "rank_update" are bracketed by HIP events on
  * the context's stream; dlco_profile_read returns launches and their summed duration.  on = 2: the gradient SYRK only
  * (two records per step; all four groups cost ~3 % of the step in event records, measured).  on = 0: off. */
 int dlco_profile_enable(dlco_ctx *ctx, int32_t on);

@@ -1331,6 +1331,7 @@ int dlco_profile_read(dlco_ctx *c, const char *kernel, int64_t *launches, double
         if (kernel && std::strcmp(kernel, "eig_product") == 0) slot = PROF_EIG_PRODUCT;
         else if (kernel && std::strcmp(kernel, "jacobi") == 0) slot = PROF_JACOBI;
         else if (kernel && std::strcmp(kernel, "project") == 0) slot = PROF_PROJECT;
+        else if (kernel && std::strcmp(kernel, "rank_update") == 0) slot = PROF_RANK_UPDATE;
         else if (kernel && std::strcmp(kernel, "grad_syrk") != 0) throw Error(DLCO_ERR_INVALID, "dlco_profile_read: unknown kernel group");
         c->prof.drain(slot);
         *launches = c->prof.rec[slot].n;

@@ -78,7 +78,7 @@ struct DevBuf {
 // ---------------------------------------------------------------------------
 // HIP-event timers on the launch stream, one slot per named kernel group
 // ---------------------------------------------------------------------------
-enum ProfSlot { PROF_GRAD_SYRK = 0, PROF_EIG_PRODUCT = 1, PROF_JACOBI = 2, PROF_PROJECT = 3, PROF_SLOTS = 4 };
+enum ProfSlot { PROF_GRAD_SYRK = 0, PROF_EIG_PRODUCT = 1, PROF_JACOBI = 2, PROF_PROJECT = 3, PROF_RANK_UPDATE = 4, PROF_SLOTS = 5 };
 
 struct Profiler {
     bool on = false;

@@ -501,9 +501,11 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                 if (it == 0 && ru_ok && n_ritz == m_) {
                     // (H - c0) Q / e0 = (beta / e0) Y - (alpha / e0) C_w X_a - (c0 / e0) Q, H = -G
                     coeff_.alloc(rank_coeff_bytes(cap_ < 160 ? cap_ : 160, ru_.kmax));
+                    if (prof_) prof_->begin(PROF_RANK_UPDATE);
                     first_done = rank_first_term(Y_, Q_, F_, m_, F_, ru_.beta / e0, -c0 / e0, -ru_.alpha / e0, cur, ru_.proj, ru_.ldp,
                                                  ru_nw, wscale_.p, ru_.slot, ru_.w, ru_.k_dev, ru_.kmax, ru_.planes, coeff_.p,
                                                  chain_next_ ? plane_hi_.p : nullptr, plane_lo_.p, s_);
+                    if (prof_) prof_->end(PROF_RANK_UPDATE);
                     if (first_done) {
                         st_.rank_update_passes++;
                         chain_planes_of_ = chain_next_ ? cur : nullptr;
