@@ -322,7 +322,7 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
 
 // dst = beta*dst_in + alpha * X^T diag(w) X over the active rows (upper triangle computed, mirrored)
 void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev, int kmax, float alpha, float beta,
-               float *dst, bool packed = false)
+               float *dst, bool packed = false, const RankCoeffJob *coeff_job = nullptr)
 {
     const int kpad = (kmax + 31) & ~31;                 // the lists are zero padded up to here
     const RowRef rr = rows_of(c, ids, 0, kpad);
@@ -334,7 +334,7 @@ void grad_syrk(dlco_ctx *c, const int32_t *ids, const float *w, const int *k_dev
         if (pbytes > c->syrk_planes.n) { sync(c); c->syrk_planes.alloc(pbytes); }
         const bool done = syrk_rda_f32(c->dists, c->F, rr.a, rr.b, w, k_dev, kpad, c->F, alpha, beta, dst, c->F, c->stream,
                                        c->shard ? c->comm.c0 : 0, c->shard ? c->comm.cw : 0, c->cfg.grad_bf16 != 0, packed,
-                                       c->syrk_planes.p);
+                                       c->syrk_planes.p, coeff_job);
         c->prof.end(PROF_GRAD_SYRK);
         DLCO_CHECK(done, DLCO_ERR_INVALID, "grad_syrk: fused kernel rejected an eligible shape");
         return;
@@ -415,7 +415,11 @@ void step_grad(dlco_ctx *c)
                             c->act_ids.p, c->act_w.p, c->k_active.p, c->stream, c->act_slot.p);
     float alpha, beta;
     rda_coeffs(c, &alpha, &beta);
-    if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed);
+    // (the coefficient fragments of the tracker's rank-update first term ride in the gradient's row-split launch)
+    RankCoeffJob job;
+    const bool have_job = c->rank_update && c->ru_proj && world == 1 && c->eig->rank_coeff_job(&job, (2 * Bl + 31) & ~31);
+    if (have_job) { job.proj = c->ru_proj; job.ldp = 2 * Bl; job.slot = c->act_slot.p; }
+    if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed, have_job ? &job : nullptr);
     else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->xgrad);
     if (c->rank_update && c->ru_proj && c->syrk_planes.p) {
         // dfAvg <- beta dfAvg + alpha X_a^T diag(w) X_a has just been applied: the tracker may form its first filter
@@ -424,6 +428,7 @@ void step_grad(dlco_ctx *c)
         ru.proj = c->ru_proj; ru.ldp = 2 * Bl; ru.rows = c->ru_rows;
         ru.slot = c->act_slot.p; ru.w = c->act_w.p; ru.k_dev = c->k_active.p; ru.kmax = (2 * Bl + 31) & ~31;
         ru.planes = c->syrk_planes.p; ru.alpha = alpha; ru.beta = beta;
+        ru.coeff_ready = have_job && job.m == c->ru_rows;
         c->eig->offer_rank_update(ru);
     }
     c->phase = 2;

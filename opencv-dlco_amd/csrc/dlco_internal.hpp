@@ -176,6 +176,16 @@ bool project_rows_sqdist(const float *W, long ldw, int r, const float *D, long l
 bool project_rows_slab(const float *W, long ldw, int r, const float *D, long ldd, int F, const int32_t *ids, const int32_t *ids2,
                        int nrows, int ksplit, float *slab, long ldn, void *plane_hi, void *plane_lo, void *plane_lo2, bool bf16,
                        hipStream_t s);
+// The coefficient fragments of the rank-update first filter term (kernels_rankupd.hip), as a job that rides in the
+// gradient's row-split launch (its extra column of blocks): frag = nullptr means no job.
+struct RankCoeffJob {
+    const float *proj = nullptr;     // [rows of W incl. guard rows][ldp] projections of the batch slots
+    long ldp = 0;
+    int nw = 0, m = 0, MT = 0;       // Ritz rows among them, rows in all, 32-row tiles
+    const float *wscale = nullptr;   // scale row i of the block went into W with
+    const int32_t *slot = nullptr;   // slot[k]: column of proj of active row k
+    void *frag = nullptr;            // out: rank_coeff_bytes(m, kmax) bytes
+};
 // Fused gradient SYRK + dual average (kernels_syrk.hip): C = beta*C + alpha * sum_k w_k x_k x_k^T over the
 // rows ids[0 .. *k_dev) of D, upper tiles computed and mirrored.  ids/w hold kmax entries (multiple of 32,
 // zero padded beyond *k_dev).  Returns false when the shape is not supported (F % 128 != 0).
@@ -192,7 +202,8 @@ void syrk_mirror_upper(float *C, long ldc, int F, hipStream_t s);
 size_t syrk_planes_bytes(int kmax, int F);
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
-                  int slab_cols = 0, bool bf16 = false, bool packed = false, void *planes_ws = nullptr);
+                  int slab_cols = 0, bool bf16 = false, bool packed = false, void *planes_ws = nullptr,
+                  const RankCoeffJob *coeff_job = nullptr);
 // true when syrk_rda_f32(bf16) writes the three-way split planes of syrk_split_rows_kernel into planes_ws (the default
 // arithmetic: not DLCO_SYRK_FP32, not the bf16-once variant): rank_first_term() reads operand 1 of them
 bool syrk_planes_are_split3(bool bf16);
@@ -203,7 +214,8 @@ bool syrk_planes_are_split3(bool bf16);
 size_t rank_coeff_bytes(int m, int kmax);
 bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, float ay, float aq, float ac, float *out,
                      const float *proj, long ldp, int nw, const float *wscale, const int32_t *slot, const float *w,
-                     const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s);
+                     const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s,
+                     bool coeff_ready = false);   // coeff_ws already holds the fragments (they rode in the gradient's row split)
 size_t syrk_packed_floats(int F);
 void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s);      // upper tiles of a full matrix -> packed
 void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s);    // packed -> full symmetric matrix

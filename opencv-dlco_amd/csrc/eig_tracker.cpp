@@ -101,6 +101,15 @@ void EigTracker::seed_rows(const float *src, long ld, const int32_t *ids_dev, in
     m_ = k;
 }
 
+bool EigTracker::rank_coeff_job(RankCoeffJob *job, int kmax)
+{
+    if (wext_rows_ <= 0 || wext_rows_ != m_ || m_ > 160 || !packed_ || !bf16_filter_ || shard_ || kmax % 32 != 0) return false;
+    coeff_.alloc(rank_coeff_bytes(cap_ < 160 ? cap_ : 160, kmax));
+    job->nw = wext_nw_; job->m = m_; job->MT = (m_ + 31) / 32;
+    job->wscale = wscale_.p; job->frag = coeff_.p;
+    return true;
+}
+
 float EigTracker::next_uniform()
 {
     rng_ ^= rng_ << 13; rng_ ^= rng_ >> 7; rng_ ^= rng_ << 17;
@@ -504,7 +513,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                     if (prof_) prof_->begin(PROF_RANK_UPDATE);
                     first_done = rank_first_term(Y_, Q_, F_, m_, F_, ru_.beta / e0, -c0 / e0, -ru_.alpha / e0, cur, ru_.proj, ru_.ldp,
                                                  ru_nw, wscale_.p, ru_.slot, ru_.w, ru_.k_dev, ru_.kmax, ru_.planes, coeff_.p,
-                                                 chain_next_ ? plane_hi_.p : nullptr, plane_lo_.p, s_);
+                                                 chain_next_ ? plane_hi_.p : nullptr, plane_lo_.p, s_, ru_.coeff_ready);
                     if (prof_) prof_->end(PROF_RANK_UPDATE);
                     if (first_done) {
                         st_.rank_update_passes++;

@@ -39,6 +39,7 @@ struct RankUpdate {
     int kmax = 0;                    // capacity of the lists (multiple of 32, zero padded)
     const void *planes = nullptr;    // syrk_split_rows_kernel's planes of the active rows
     float alpha = 0.f, beta = 1.f;
+    bool coeff_ready = false;        // the coefficient fragments were written by the gradient's row split (rank_coeff_job)
 };
 
 class EigTracker {
@@ -80,6 +81,9 @@ public:
     int ext_rows() const { return wext_rows_; }          // rows of W the last update() wrote, guard rows included (0: none)
     // consumed by the next update() only; ignored when the block is not the one the projection was made with
     void offer_rank_update(const RankUpdate &ru) { ru_ = ru; ru_offered_ = true; }
+    // The part of the coefficient job the tracker knows (rows, scales, output buffer) for a row list of capacity kmax;
+    // false when the block is not one the shortcut takes.  The caller adds proj / slot and lets the job ride in its gradient.
+    bool rank_coeff_job(RankCoeffJob *job, int kmax);
     void set_packed(bool on) { packed_ = on; }
     bool packed() const { return packed_; }
     static bool packed_supported(int F) { return F % 128 == 0 && F / 128 <= 64 && std::getenv("DLCO_FP32_FILTER") == nullptr && std::getenv("DLCO_FP32_RR") == nullptr && std::getenv("DLCO_NO_PACKED") == nullptr; }

@@ -21,6 +21,7 @@
 // Only the filter is fed this way - it enriches a subspace; the Rayleigh-Ritz product, the residuals and the convergence
 // test still use the matrix itself, so a stale Y could cost passes, never a wrong result.
 #include "dlco_internal.hpp"
+#include "rank_coeff_dev.hpp"
 
 namespace dlco {
 
@@ -34,36 +35,14 @@ constexpr int RU_TB = 128;                    // column tile of the gradient's p
 constexpr int RU_KD = 16;                     // rows per K block there (PL_KD)
 constexpr int RU_IMG = 3 * 2 * RU_TB * 16;    // bytes of one (operand, K block, column tile) image (PL_IMG)
 
-// Coefficient fragments, two-way split, in MFMA A-operand order: entry ((kb * MT + tile) * 2 + plane) * 64 + lane holds
-// C_w[tile*32 + (lane & 31)][kb*16 + 8*(lane >> 5) .. + 7].  proj is the step's projection [rows of W_ext][ldp] of the
-// batch slots: row nw-1-i of it is s_i (q_i . x) for a Ritz row i < nw (W is in ascending order, src/pj-learn.cpp:480-484),
-// row i is q_i . x for a guard row; wscale[i] = s_i (1 for guards).
-__global__ __launch_bounds__(64) void rank_coeff_kernel(const float *proj, long ldp, int nw, int m, const float *wscale,
-                                                        const int32_t *slot, const float *w, const int *k_dev, int kmax, int MT,
-                                                        bf16x8 *frag)
+// Coefficient fragments (rank_coeff_dev.hpp) as a launch of their own: one block of 64 lanes per (K block, row tile).  The
+// trainer's steps let them ride in the gradient's row-split launch instead (RankCoeffJob).
+__global__ __launch_bounds__(64) void rank_coeff_kernel(RankCoeffJob job, const float *w, const int *k_dev, int kmax)
 {
-    const int kb = blockIdx.x, tile = blockIdx.y, lane = threadIdx.x;
+    const int kb = blockIdx.x, tile = blockIdx.y;
     const int kact = min(*k_dev, kmax);
     if (kb * RU_KD >= kact) return;
-    const int i = tile * 32 + (lane & 31), k0 = kb * RU_KD + 8 * (lane >> 5);
-    bf16x8 h, l;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { h[j] = (__bf16)0.f; l[j] = (__bf16)0.f; }
-    if (i < m) {
-        const float *prow = proj + (long)(i < nw ? nw - 1 - i : i) * ldp;
-        const float inv = 1.0f / wscale[i];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = k0 + j;
-            float v = 0.f;
-            if (k < kact) v = w[k] * (prow[slot[k]] * inv);
-            h[j] = (__bf16)v;
-            l[j] = (__bf16)(v - (float)h[j]);
-        }
-    }
-    bf16x8 *o = frag + ((long)(kb * MT + tile) * 2) * 64 + lane;
-    o[0] = h;
-    o[64] = l;
+    rank_coeff_block(job, w, kact, kb, tile, threadIdx.x);
 }
 
 struct RankUpdDev {
@@ -202,14 +181,18 @@ size_t rank_coeff_bytes(int m, int kmax) { return (size_t)(kmax / RU_KD) * ((m +
 // shapes the kernels do not take (the caller then forms the term with a product over the matrix).
 bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, float ay, float aq, float ac, float *out,
                      const float *proj, long ldp, int nw, const float *wscale, const int32_t *slot, const float *w,
-                     const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s)
+                     const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s,
+                     bool coeff_ready)
 {
     const int mt = (m + 31) / 32;
     if (m < 1 || mt > 5 || F % 128 != 0 || kmax % 32 != 0 || kmax < 32) return false;
     if (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Q) & 15) != 0 ||
         (reinterpret_cast<uintptr_t>(out) & 15) != 0) return false;
-    hipLaunchKernelGGL(rank_coeff_kernel, dim3(kmax / RU_KD, mt), dim3(64), 0, s, proj, ldp, nw, m, wscale, slot, w, k_dev, kmax, mt,
-                       static_cast<bf16x8 *>(coeff_ws));
+    if (!coeff_ready) {
+        RankCoeffJob job;
+        job.proj = proj; job.ldp = ldp; job.nw = nw; job.m = m; job.MT = mt; job.wscale = wscale; job.slot = slot; job.frag = coeff_ws;
+        hipLaunchKernelGGL(rank_coeff_kernel, dim3(kmax / RU_KD, mt), dim3(64), 0, s, job, w, k_dev, kmax);
+    }
     RankUpdDev g;
     g.Y = Y; g.Q = Q; g.out = out; g.ld = ld;
     g.frag = static_cast<const bf16x8 *>(coeff_ws);

@@ -15,6 +15,7 @@
 // fmaf chain (DLCO_SYRK_FP32=1); operands rounded to bf16 once (cfg.grad_bf16, BASELINE configs[4]) go through
 // the same two new kernels (syrk_round_rows_kernel).  Epilogue everywhere: dual-average update in registers.
 #include "dlco_internal.hpp"
+#include "rank_coeff_dev.hpp"
 
 #include <mutex>
 #include <type_traits>
@@ -274,12 +275,19 @@ constexpr int PL_IMG = 3 * 2 * TB * 16;   // bytes of one (operand, K block, col
 constexpr int PL_STAGE = 2 * PL_IMG;      // A image + B image
 constexpr int NTP = 256;
 
+// (coeff.frag != nullptr: the launch has one more column of blocks, which writes the coefficient fragments of the
+// tracker's rank-update first term for their K block - a by-product of the same row list, see kernels_rankupd.hip)
 __global__ __launch_bounds__(256) void syrk_split_rows_kernel(const float *D, long ldd, const int32_t *ids, const int32_t *ids2,
-                                                              const float *w, const int *k_dev, int kmax, int nt, char *planes)
+                                                              const float *w, const int *k_dev, int kmax, int nt, char *planes,
+                                                              RankCoeffJob coeff)
 {
     const int ct = blockIdx.x, kb = blockIdx.y;
     const int kact = min(*k_dev, kmax);
     if (kb * PL_KD >= kact) return;
+    if (ct == nt) {
+        for (int tile = threadIdx.x >> 6; tile < coeff.MT; tile += 4) rank_coeff_block(coeff, w, kact, kb, tile, threadIdx.x & 63);
+        return;
+    }
     const int col = threadIdx.x & (TB - 1), lk = threadIdx.x >> 7;
     const int nkb = kmax / PL_KD;
     float v[8], wv[8];
@@ -655,7 +663,7 @@ static char *syrk_planes_buffer(size_t bytes)
 
 bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *ids2, const float *w, const int *k_dev,
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0, int slab_cols, bool bf16,
-                  bool packed, void *planes_ws)
+                  bool packed, void *planes_ws, const RankCoeffJob *coeff_job)
 {
     if (F % TB != 0 || kmax % KB != 0 || ldd % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0) return false;
     const bool slab = slab_cols > 0;
@@ -690,7 +698,8 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
         // the caller's workspace (a context owns one: launches of two contexts on two streams must not share planes), or
         // the per-device one for callers without (developer tools: one stream)
         char *planes = planes_ws ? static_cast<char *>(planes_ws) : syrk_planes_buffer(syrk_planes_bytes(kmax, F));
-        if (prec == 3) hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt, kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
+        const RankCoeffJob job = (coeff_job && prec == 3) ? *coeff_job : RankCoeffJob();
+        if (prec == 3) hipLaunchKernelGGL(syrk_split_rows_kernel, dim3(g.nt + (job.frag ? 1 : 0), kmax / PL_KD), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes, job);
         else hipLaunchKernelGGL(syrk_round_rows_kernel, dim3(g.nt, (kmax + 3 * PL_KD - 1) / (3 * PL_KD)), dim3(256), 0, s, D, ldd, ids, ids2, w, k_dev, kmax, g.nt, planes);
         // three stages of 24 KB, two workgroups per CU.  (Two stages and three workgroups per CU - twelve waves - measured
         // the same: 0.133 against 0.132 ms per launch; so did eight waves of 64 x 32 per tile: 0.137 against 0.133.  What the launch loses is spread over the K loop, where two
