@@ -65,6 +65,7 @@ struct dlco_ctx {
     // the step's first filter term from its own rank update (kernels_rankupd.hip): the batch projection also covers the
     // tracker's guard rows, and what the tracker needs of the step is handed over after the gradient
     bool rank_update = false;
+    int planes_mode = 0;             // syrk_planes_mode(): which planes the gradient leaves for the rank update
     const float *ru_proj = nullptr;  // this step's projection [ru_rows][2 Bl] of the batch on the rows of W (guards included)
     int ru_rows = 0;
     DevBuf<float> act_w, seed_w, dist_x, pd, nd, proj_slab, vproj, vdist, hrows;
@@ -281,22 +282,29 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
     if (n <= 0) return;
     if (r <= 0) { fill_f32(out_dev, 0.f, (size_t)n, c->stream); return; }
     const int rp = std::max(r, r_ext);
-    if (c->cfg.grad_bf16 && r <= 96 && c->F % 64 == 0) {
+    if (c->cfg.grad_bf16 && rp <= 96 && c->F % 64 == 0) {
         // BASELINE configs[4] variant: the batch projection on the bf16 matrix cores too (operands rounded to bf16 once,
         // fp32 accumulation), K split over enough slices to fill the chip, slices summed in order
         const int blocks = (n + 127) / 128;
         int ks = 1;
         while (ks * 2 * blocks <= 256 && (c->F / 64) % (ks * 2) == 0) ks *= 2;
-        const size_t need = (size_t)ks * r * n;
-        if (need > c->proj_slab_floats) { c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+        const size_t need = (size_t)(ks + 1) * rp * n;
+        if (need > c->proj_slab_floats) { sync(c); c->proj_slab.alloc(need); c->proj_slab_floats = need; }
+        float *reduced = rp > r ? c->proj_slab.p + (size_t)ks * rp * n : nullptr;   // [rp][n] behind the slabs: what the rank update reads
         for (auto &pl : c->pplane) pl.alloc(project_rows_plane_bytes(c->F));
         const RowRef rr = rows_of(c, ids_dev, 0, n);
         c->prof.begin(PROF_PROJECT);
-        const bool ok = project_rows_slab(Wd, c->F, r, c->dists, c->F, c->F, rr.a, rr.b, n, ks, c->proj_slab.p, n, c->pplane[0].p,
+        const bool ok = project_rows_slab(Wd, c->F, rp, c->dists, c->F, c->F, rr.a, rr.b, n, ks, c->proj_slab.p, n, c->pplane[0].p,
                                           c->pplane[1].p, c->pplane[2].p, true, c->stream);
-        if (ok) sqdist_from_proj(c->proj_slab.p, ks, r, n, n, out_dev, c->stream);
+        if (ok) {
+            if (ks > 2) sqdist_from_proj(c->proj_slab.p, ks, r, n, n, out_dev, c->stream, rp, reduced);
+            else { sqdist_from_proj(c->proj_slab.p, ks, r, n, n, out_dev, c->stream); reduced = nullptr; }   // (never with F >= 256)
+        }
         c->prof.end(PROF_PROJECT);
-        if (ok) return;
+        if (ok) {
+            if (reduced) { c->ru_proj = reduced; c->ru_rows = rp; }
+            return;
+        }
     }
     static const bool small_tiles = std::getenv("DLCO_PROJ_BIG_TILES") == nullptr;
     const int bm = (rp <= 64 || (small_tiles && rp <= 128)) ? 64 : 128, bn = n <= 64 ? 64 : 128;
@@ -417,7 +425,8 @@ void step_grad(dlco_ctx *c)
     rda_coeffs(c, &alpha, &beta);
     // (the coefficient fragments of the tracker's rank-update first term ride in the gradient's row-split launch)
     RankCoeffJob job;
-    const bool have_job = c->rank_update && c->ru_proj && world == 1 && c->eig->rank_coeff_job(&job, (2 * Bl + 31) & ~31);
+    // (the bf16-once variant's row kernel has no such column: its fragments take a launch of their own)
+    const bool have_job = c->rank_update && c->planes_mode == 3 && c->ru_proj && world == 1 && c->eig->rank_coeff_job(&job, (2 * Bl + 31) & ~31);
     if (have_job) { job.proj = c->ru_proj; job.ldp = 2 * Bl; job.slot = c->act_slot.p; }
     if (world == 1) grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, alpha, beta, c->dfavg.p, c->packed, have_job ? &job : nullptr);
     else grad_syrk(c, c->act_ids.p, c->act_w.p, c->k_active.p, 2 * Bl, 1.0f, 0.0f, c->xgrad);
@@ -429,6 +438,7 @@ void step_grad(dlco_ctx *c)
         ru.slot = c->act_slot.p; ru.w = c->act_w.p; ru.k_dev = c->k_active.p; ru.kmax = (2 * Bl + 31) & ~31;
         ru.planes = c->syrk_planes.p; ru.alpha = alpha; ru.beta = beta;
         ru.coeff_ready = have_job && job.m == c->ru_rows;
+        ru.planes_mode = c->planes_mode;
         c->eig->offer_rank_update(ru);
     }
     c->phase = 2;
@@ -623,8 +633,8 @@ int dlco_ctx_create(dlco_ctx **out, const dlco_cfg *cfg)
         const int kcap = (2 * B + 31) & ~31;                      // row lists are zero padded to whole K tiles
         c->act_ids.alloc(kcap); c->act_w.alloc(kcap); c->seed_ids.alloc(kcap); c->seed_w.alloc(kcap); c->act_slot.alloc(kcap);
         // one rank, packed dual average, the gradient's default arithmetic (its split planes are what the shortcut reads)
-        c->rank_update = c->packed && cfg->world == 1 && syrk_planes_are_split3(cfg->grad_bf16 != 0) &&
-                         std::getenv("DLCO_NO_RANK_UPDATE") == nullptr;
+        c->planes_mode = syrk_planes_mode(cfg->grad_bf16 != 0);
+        c->rank_update = c->packed && cfg->world == 1 && c->planes_mode != 0 && std::getenv("DLCO_NO_RANK_UPDATE") == nullptr;
         c->eig->set_emit_guards(c->rank_update);
         c->dist_x.alloc(2 * B); c->pd.alloc(B); c->nd.alloc(B);
         c->xdist = c->dist_x.p; c->xgrad = c->grad.p;

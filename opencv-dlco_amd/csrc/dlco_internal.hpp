@@ -204,9 +204,8 @@ bool syrk_rda_f32(const float *D, long ldd, const int32_t *ids, const int32_t *i
                   int kmax, int F, float alpha, float beta, float *C, long ldc, hipStream_t s, int slab_col0 = 0,
                   int slab_cols = 0, bool bf16 = false, bool packed = false, void *planes_ws = nullptr,
                   const RankCoeffJob *coeff_job = nullptr);
-// true when syrk_rda_f32(bf16) writes the three-way split planes of syrk_split_rows_kernel into planes_ws (the default
-// arithmetic: not DLCO_SYRK_FP32, not the bf16-once variant): rank_first_term() reads operand 1 of them
-bool syrk_planes_are_split3(bool bf16);
+// which planes syrk_rda_f32(bf16) writes into planes_ws: rank_first_term() reads operand 1 of them
+int syrk_planes_mode(bool bf16);     // 3: three-way split planes (default arithmetic), 1: bf16-once planes (cfg.grad_bf16), 0: no planes (DLCO_SYRK_FP32)
 // The first Chebyshev term of a step's filter from the step's own rank update, without a pass over the matrix
 // (kernels_rankupd.hip): out = ay*Y + aq*Q + ac * C_w X_a, C_w[i][k] = w[k] * proj[row(i)][slot[k]] / wscale[i] with
 // row(i) = nw-1-i for i < nw (W's ascending order), i for the guard rows behind; X_a = operand 1 of `planes`; also emits
@@ -215,7 +214,7 @@ size_t rank_coeff_bytes(int m, int kmax);
 bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, float ay, float aq, float ac, float *out,
                      const float *proj, long ldp, int nw, const float *wscale, const int32_t *slot, const float *w,
                      const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s,
-                     bool coeff_ready = false);   // coeff_ws already holds the fragments (they rode in the gradient's row split)
+                     bool coeff_ready = false, int planes_mode = 3);   // coeff_ws already holds the fragments (they rode in the gradient's row split)
 size_t syrk_packed_floats(int F);
 void syrk_pack_upper(const float *C, long ldc, int F, float *packed, hipStream_t s);      // upper tiles of a full matrix -> packed
 void syrk_unpack_upper(const float *packed, int F, float *C, long ldc, hipStream_t s);    // packed -> full symmetric matrix
@@ -239,7 +238,8 @@ void splitk_reduce_f32(const float *slab, int split, int M, int N, float *C, lon
 // step kernels (kernels_step.hip)
 // ---------------------------------------------------------------------------
 // dist[j] = sum_q (sum_z slab[z][q][j])^2 for a [split][r][n] projection slab
-void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s);
+void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s, int r_all = 0,
+                      float *reduced = nullptr);   // r_all > r (slab form): the slabs hold r_all rows, all reduced into `reduced`, the first r summed
 // rho/kappa + signed weights + compact active list for one batch
 //   pd, nd: [B] distances; out rho[B], kappa[B]; weights[2B] (rho_i for positives, -kappa_j for negatives)
 void viol_counts(const float *pd, const float *nd, int B, int32_t *rho, int32_t *kappa, hipStream_t s);

@@ -513,7 +513,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
                     if (prof_) prof_->begin(PROF_RANK_UPDATE);
                     first_done = rank_first_term(Y_, Q_, F_, m_, F_, ru_.beta / e0, -c0 / e0, -ru_.alpha / e0, cur, ru_.proj, ru_.ldp,
                                                  ru_nw, wscale_.p, ru_.slot, ru_.w, ru_.k_dev, ru_.kmax, ru_.planes, coeff_.p,
-                                                 chain_next_ ? plane_hi_.p : nullptr, plane_lo_.p, s_, ru_.coeff_ready);
+                                                 chain_next_ ? plane_hi_.p : nullptr, plane_lo_.p, s_, ru_.coeff_ready, ru_.planes_mode);
                     if (prof_) prof_->end(PROF_RANK_UPDATE);
                     if (first_done) {
                         st_.rank_update_passes++;

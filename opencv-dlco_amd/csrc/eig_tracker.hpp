@@ -39,6 +39,7 @@ struct RankUpdate {
     int kmax = 0;                    // capacity of the lists (multiple of 32, zero padded)
     const void *planes = nullptr;    // syrk_split_rows_kernel's planes of the active rows
     float alpha = 0.f, beta = 1.f;
+    int planes_mode = 3;             // syrk_planes_mode(): 3 = three-way split planes, 1 = bf16-once planes
     bool coeff_ready = false;        // the coefficient fragments were written by the gradient's row split (rank_coeff_job)
 };
 

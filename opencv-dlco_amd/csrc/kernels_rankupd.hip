@@ -65,7 +65,11 @@ struct RankUpdDev {
 // five MFMAs (ah*bh, ah*bm, al*bh, ah*bl, al*bm: everything down to 2^-24 of the two-way coefficient).  The KS partial
 // tiles meet in LDS; one thread per plane entry (a row's eight consecutive columns) then forms ay*Y + aq*Q + ac*sum - its
 // Y and Q values requested before the K loop - and stores the row segment and the two plane entries.
-template <int MT, int KS>
+// MODE 3: the three-way planes of syrk_split_rows_kernel (one 12 KB image per 16-row block: hi, mid, lo).  MODE 1: the bf16-once
+// planes of syrk_round_rows_kernel (cfg.grad_bf16: one image per 48-row block, its three slots = three 16-row sub-blocks of
+// values rounded once) - two MFMAs per block; the update the gradient applied was formed from these rounded values, and the
+// projections were rounded the same way, so the term is exact to the 2^-9 of that arithmetic in its (1/t-sized) update part.
+template <int MT, int KS, int MODE>
 __global__ __launch_bounds__(64 * MT * KS) void rank_first_term_kernel(RankUpdDev g)
 {
     __shared__ float P[KS][MT * 32][36];
@@ -98,14 +102,17 @@ __global__ __launch_bounds__(64 * MT * KS) void rank_first_term_kernel(RankUpdDe
         for (int u = 0; u < 4; u++) {
             const int k = kb + u * KS;
             ah[u] = af[k * astride]; al[u] = af[k * astride + 64];
-            bh[u] = xb[k * xstride]; bm[u] = xb[k * xstride + 2 * RU_TB]; bl[u] = xb[k * xstride + 4 * RU_TB];
+            if (MODE == 3) { bh[u] = xb[k * xstride]; bm[u] = xb[k * xstride + 2 * RU_TB]; bl[u] = xb[k * xstride + 4 * RU_TB]; }
+            else bh[u] = xb[(k / 3) * xstride + (k % 3) * 2 * RU_TB];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bm[u], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
+            if (MODE == 3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bm[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[u], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bm[u], acc, 0, 0, 0);
+            if (MODE == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bm[u], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[u], acc, 0, 0, 0);
         }
     }
@@ -117,16 +124,19 @@ __global__ __launch_bounds__(64 * MT * KS) void rank_first_term_kernel(RankUpdDe
             const int k = kb + u * KS;
             if (k < nkb) {
                 ah[u] = af[k * astride]; al[u] = af[k * astride + 64];
-                bh[u] = xb[k * xstride]; bm[u] = xb[k * xstride + 2 * RU_TB]; bl[u] = xb[k * xstride + 4 * RU_TB];
+                if (MODE == 3) { bh[u] = xb[k * xstride]; bm[u] = xb[k * xstride + 2 * RU_TB]; bl[u] = xb[k * xstride + 4 * RU_TB]; }
+                else bh[u] = xb[(k / 3) * xstride + (k % 3) * 2 * RU_TB];
             }
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             if (kb + u * KS < nkb) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bm[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
+                if (MODE == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bm[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl[u], acc, 0, 0, 0);
+                }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bm[u], acc, 0, 0, 0);
+                if (MODE == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bm[u], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh[u], acc, 0, 0, 0);
             }
         }
@@ -168,9 +178,10 @@ __global__ __launch_bounds__(64 * MT * KS) void rank_first_term_kernel(RankUpdDe
 }
 
 template <int MT, int KS>
-void launch_first_term(const RankUpdDev &g, hipStream_t s)
+void launch_first_term(const RankUpdDev &g, int mode, hipStream_t s)
 {
-    hipLaunchKernelGGL((rank_first_term_kernel<MT, KS>), dim3(g.F / 32), dim3(64 * MT * KS), 0, s, g);
+    if (mode == 3) hipLaunchKernelGGL((rank_first_term_kernel<MT, KS, 3>), dim3(g.F / 32), dim3(64 * MT * KS), 0, s, g);
+    else hipLaunchKernelGGL((rank_first_term_kernel<MT, KS, 1>), dim3(g.F / 32), dim3(64 * MT * KS), 0, s, g);
 }
 
 }  // namespace
@@ -182,8 +193,9 @@ size_t rank_coeff_bytes(int m, int kmax) { return (size_t)(kmax / RU_KD) * ((m +
 bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, float ay, float aq, float ac, float *out,
                      const float *proj, long ldp, int nw, const float *wscale, const int32_t *slot, const float *w,
                      const int *k_dev, int kmax, const void *planes, void *coeff_ws, void *plane_hi, void *plane_lo, hipStream_t s,
-                     bool coeff_ready)
+                     bool coeff_ready, int planes_mode)
 {
+    if (planes_mode != 3 && planes_mode != 1) return false;
     const int mt = (m + 31) / 32;
     if (m < 1 || mt > 5 || F % 128 != 0 || kmax % 32 != 0 || kmax < 32) return false;
     if (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Q) & 15) != 0 ||
@@ -201,11 +213,11 @@ bool rank_first_term(const float *Y, const float *Q, long ld, int m, int F, floa
     g.m = m; g.F = F; g.ay = ay; g.aq = aq; g.ac = ac;
     g.hi = static_cast<bf16x8 *>(plane_hi); g.lo = static_cast<bf16x8 *>(plane_lo);
     switch (mt) {
-    case 1: launch_first_term<1, 4>(g, s); break;
-    case 2: launch_first_term<2, 4>(g, s); break;
-    case 3: launch_first_term<3, 4>(g, s); break;
-    case 4: launch_first_term<4, 2>(g, s); break;
-    default: launch_first_term<5, 2>(g, s); break;
+    case 1: launch_first_term<1, 4>(g, planes_mode, s); break;
+    case 2: launch_first_term<2, 4>(g, planes_mode, s); break;
+    case 3: launch_first_term<3, 4>(g, planes_mode, s); break;
+    case 4: launch_first_term<4, 2>(g, planes_mode, s); break;
+    default: launch_first_term<5, 2>(g, planes_mode, s); break;
     }
     DLCO_HIP(hipGetLastError());
     return true;

@@ -46,15 +46,18 @@ __global__ void sqdist_kernel(const float *proj, int split, int r, int n, long l
 // thread per column would add split * r values one after the other (1 ms at 32 x 61).  A workgroup takes 64 columns; eight
 // groups of 64 threads sum the slices (in slice order) of eight rows q at a time into LDS, then the first 64 threads add
 // the squares row after row - the same two orders as above.
-__global__ __launch_bounds__(512) void sqdist_split_kernel(const float *proj, int split, int r, int n, long ld, float *dist)
+// r_all > r: the slabs hold r_all rows (the tracker's guard rows behind the r rows of W); all of them are reduced and written
+// to `reduced` [r_all][ld] (what the rank update of kernels_rankupd.hip reads), the distances sum the first r.
+__global__ __launch_bounds__(512) void sqdist_split_kernel(const float *proj, int split, int r, int n, long ld, float *dist, int r_all,
+                                                           float *reduced)
 {
     __shared__ float p[96][64];
     const int jl = threadIdx.x & 63, qg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;
-    const long plane = (long)r * ld;
+    const long plane = (long)r_all * ld;
     float d = 0.f;
-    for (int q0 = 0; q0 < r; q0 += 96) {
-        const int qn = min(96, r - q0);
+    for (int q0 = 0; q0 < r_all; q0 += 96) {
+        const int qn = min(96, r_all - q0);
         for (int q = qg; q < qn; q += 8) {
             float acc = 0.f;
             if (j < n) {
@@ -70,10 +73,11 @@ __global__ __launch_bounds__(512) void sqdist_split_kernel(const float *proj, in
                 for (; z < split; z++) acc += src[z * plane];
             }
             p[q][jl] = acc;
+            if (reduced && j < n) reduced[(long)(q0 + q) * ld + j] = acc;
         }
         __syncthreads();
         if (qg == 0)
-            for (int q = 0; q < qn; q++) d += p[q][jl] * p[q][jl];
+            for (int q = 0; q < min(qn, r - q0); q++) d += p[q][jl] * p[q][jl];
         __syncthreads();
     }
     if (qg == 0 && j < n) dist[j] = d;
@@ -326,10 +330,11 @@ __global__ __launch_bounds__(256) void synth_kernel(float *D, int N, int F, long
 
 }  // namespace
 
-void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s)
+void sqdist_from_proj(const float *proj, int split, int r, int n, long ld, float *dist, hipStream_t s, int r_all, float *reduced)
 {
     if (n <= 0) return;
-    if (split > 2) hipLaunchKernelGGL(sqdist_split_kernel, dim3((n + 63) / 64), dim3(512), 0, s, proj, split, r, n, ld, dist);
+    DLCO_CHECK(r_all <= r || split > 2, -2, "sqdist_from_proj: extra rows need the slab form");
+    if (split > 2) hipLaunchKernelGGL(sqdist_split_kernel, dim3((n + 63) / 64), dim3(512), 0, s, proj, split, r, n, ld, dist, std::max(r, r_all), reduced);
     else hipLaunchKernelGGL(sqdist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, proj, split, r, n, ld, dist);
     DLCO_HIP(hipGetLastError());
 }

@@ -631,7 +631,7 @@ static const int32_t *syrk_tile_map(int nt, int slab_t0, int slab_nt, int *count
 }
 
 
-bool syrk_planes_are_split3(bool bf16) { return !bf16 && std::getenv("DLCO_SYRK_FP32") == nullptr; }
+int syrk_planes_mode(bool bf16) { return bf16 ? 1 : (std::getenv("DLCO_SYRK_FP32") == nullptr ? 3 : 0); }
 
 size_t syrk_planes_bytes(int kmax, int F) { return (size_t)2 * (kmax / PL_KD) * (F / TB) * PL_IMG; }
 

@@ -520,6 +520,9 @@ def test_pair_mode_bit_identical_to_row_mode(dlco, F, B):
         for k in ("pos_rows", "neg_rows", "pd", "nd", "rho", "kappa"):
             assert np.array_equal(ba[k], bb[k]), k
     assert np.array_equal(row.dfavg(), par.dfavg())
+    # (the tracker's rank-update first term reads the gradient's planes, which pair mode forms from two descriptor rows)
+    ca, cb = row.counters(), par.counters()
+    assert ca["rank_update_passes"] == cb["rank_update_passes"] and (F % 128 != 0 or ca["rank_update_passes"] >= 6), (ca, cb)
     Wa, Wb = row.W(), par.W()
     assert Wa.shape == Wb.shape and np.array_equal(Wa, Wb)
     assert row.validate() == par.validate()

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$T
 mkdir -p $OUT
 for v in "$@"; do
   n=${v%%=*}
-  env $v python3 $ROOT/bench.py --config $CFG --no-cpu-baseline --reference-iters 0 --no-other-configs > $OUT/ab_$n.json 2> $OUT/ab_$n.err || { echo "$n failed"; tail -5 $OUT/ab_$n.err; continue; }
+  env $v python3 $ROOT/bench.py $AB_EXTRA --config $CFG --no-cpu-baseline --reference-iters 0 --no-other-configs > $OUT/ab_$n.json 2> $OUT/ab_$n.err || { echo "$n failed"; tail -5 $OUT/ab_$n.err; continue; }
   python3 - $OUT/ab_$n.json $n <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

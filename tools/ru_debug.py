@@ -14,7 +14,7 @@ nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 mu = float(sys.argv[3]) if len(sys.argv) > 3 else 0.004
 N, B, gamma = 4000, 200, 0.5
 D, L = synth(N, F, k=20, seed=9)
-ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma)
+ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma, grad_bf16=int(os.environ.get("RU_DEBUG_BF16", "0")))
 ctx.set_data(D, L)
 prev = ctx.eig_stats()
 for s in range(nstep):
