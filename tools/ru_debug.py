@@ -18,10 +18,15 @@ ctx = dlco.Context(F, N, B=B, mu=mu, gamma=gamma, grad_bf16=int(os.environ.get("
 ctx.set_data(D, L)
 prev = ctx.eig_stats()
 for s in range(nstep):
+    Wp = ctx.W()
     ctx.step()
+    b = ctx.batch()                        # the step's distances against |W_prev x|^2 in float64
+    pd = ((D[b["pos_rows"]].astype(np.float64) @ Wp.T.astype(np.float64)) ** 2).sum(1)
+    nd = ((D[b["neg_rows"]].astype(np.float64) @ Wp.T.astype(np.float64)) ** 2).sum(1)
+    derr = max(np.abs(b["pd"] - pd).max(), np.abs(b["nd"] - nd).max()) / max(pd.max(), nd.max(), 1e-30)
     Ap, W, _ = ref.psd_project(ref.dual_to_primal(ctx.dfavg(), mu, gamma, s))
     e = relmax(ctx.A(), Ap)
     st, cn = ctx.eig_stats(), ctx.counters()
-    print("step %2d rank %3d/%3d err %.2e passes %d rows %d block %d ru %d chk %.2e locked %d/%d" % (s, ctx.W().shape[0], W.shape[0], e, st["iters"] - prev["iters"],
-          st["product_rows"] - prev["product_rows"], st["block_rows"], cn["rank_update_passes"], cn["rank_update_check"], cn["locked_passes"], cn["locked_rows"]))
+    print("step %2d rank %3d/%3d err %.2e passes %d rows %d block %d ru %d chk %.2e locked %d/%d dist %.1e" % (s, ctx.W().shape[0], W.shape[0], e, st["iters"] - prev["iters"],
+          st["product_rows"] - prev["product_rows"], st["block_rows"], cn["rank_update_passes"], cn["rank_update_check"], cn["locked_passes"], cn["locked_rows"], derr))
     prev = st
