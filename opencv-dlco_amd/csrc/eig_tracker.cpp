@@ -727,6 +727,15 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         int keep = nw + guard_;
         const int r32 = (keep / 32) * 32;
         if (r32 >= nw + std::max(4, guard_ / 2)) keep = r32;
+        else if (keep <= 96) {
+            // the m x m solvers work on PAIRS of eight-column blocks (kernels_jacobi.hip): 81-96 rows cost eleven block rounds
+            // per sweep, 65-80 rows nine.  A small block - where that chain is half the step - that can drop to a multiple of
+            // 16 rows and keep three quarters of its guards does (the reference's own shape: rank 55 + 32 guards = 87 rows
+            // -> 80; Jacobi 0.117 -> 0.100 ms, 1.005 -> 1.015 passes per step, +3.5 % on ref544).  Not above 96 rows: at rank
+            // ~115 the same rule (152 -> 144 rows, 24 guards) cost more passes than it saved rounds (1.16 -> 1.24 per step).
+            const int r16 = (keep / 16) * 16;
+            if (r16 >= nw + std::max(4, (3 * guard_) / 4)) keep = r16;
+        }
         m_ = std::max(1, std::min(m_, keep));
     }
     double tr = 0.0;
