@@ -684,8 +684,9 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         // error of A+ then sits 3-10x below it; one that needed more passes (start-up transient, a growing block) has
         // nothing to lean on and stops right at the tolerance (free runs against ssyevr step by step: up to 1.03e-4 of
         // the 1e-4 gate at eig_tol = 2e-4).  Passes after the first therefore converge to half of it.
-        // (And a first pass that stops right AT the tolerance was measured at 0.46 of it in A+ - 9.2e-5 against the 1e-4 gate -
-        // so the first pass is held to three quarters: the adaptive degree then settles one notch higher where it must.)
+        // (And a first pass that stops right AT the tolerance was measured at 0.46 of it in A+ - 9.2e-5 against the 1e-4 gate, in a
+        // small free run; at full width the ratio is 0.25-0.29, tools/full_width_crit_vs_error.py - so the first pass is held to
+        // 0.85 of it: worst free-run step 7.4e-5, and the rank ~128 workload pays 1.12 instead of 1.11 passes per step.)
         else conv = crit <= (it == 0 ? tol_pass1_ * tol : tol_pass2_ * tol) * emax && guards_ok;
         if (debug_)
             std::fprintf(stderr, "[eig] upd %ld it %d deg %d lock %d m %d nw %d theta[%.5g .. %.5g] mu %.5g lo %.5g crit/emax %.3g guards_ok %d conv %d\n",

@@ -137,7 +137,7 @@ private:
     bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
     float cheap_margin_ = std::getenv("DLCO_CHEAP_MARGIN") ? (float)std::atof(std::getenv("DLCO_CHEAP_MARGIN")) : 1.6f;
     bool lock_ = std::getenv("DLCO_NO_LOCKING") == nullptr;           // see update(): converged top pairs leave the filter
-    float tol_pass1_ = std::getenv("DLCO_EIG_TOL_PASS1") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS1")) : 0.75f;  // ... and of the first
+    float tol_pass1_ = std::getenv("DLCO_EIG_TOL_PASS1") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS1")) : 0.85f;  // ... and of the first
     float tol_pass2_ = std::getenv("DLCO_EIG_TOL_PASS2") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS2")) : 0.5f;   // see update(): tolerance factor of the passes after the first
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
