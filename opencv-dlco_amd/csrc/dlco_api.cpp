@@ -306,8 +306,7 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
             return;
         }
     }
-    static const bool small_tiles = std::getenv("DLCO_PROJ_BIG_TILES") == nullptr;
-    const int bm = (rp <= 64 || (small_tiles && rp <= 128)) ? 64 : 128, bn = n <= 64 ? 64 : 128;
+    const int bm = rp <= 128 ? 64 : 128, bn = n <= 64 ? 64 : 128;    // (a 96-row block: two 64-row tiles or one of 128 measured the same, 25 us)
     const long tiles = (long)((rp + bm - 1) / bm) * ((n + bn - 1) / bn);
     long split = std::max(1L, std::min((512 + tiles - 1) / tiles, (long)c->F / 128));
     const size_t need = (size_t)(split + 1) * rp * n;

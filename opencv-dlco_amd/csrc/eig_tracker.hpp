@@ -135,10 +135,10 @@ private:
     int last_deg_ = 0;               // degree actually used by the last filter (after the amplification cap)
     bool y_ok_ = false;              // Y_ = Q_ * H row for row for the matrix of the current update
     bool cheap_pass_ = std::getenv("DLCO_NO_CHEAP_PASS") == nullptr;
-    float cheap_margin_ = std::getenv("DLCO_CHEAP_MARGIN") ? (float)std::atof(std::getenv("DLCO_CHEAP_MARGIN")) : 1.6f;
+    float cheap_margin_ = 1.6f;         // see update(): how narrow a miss must be for a pass without products
     bool lock_ = std::getenv("DLCO_NO_LOCKING") == nullptr;           // see update(): converged top pairs leave the filter
     float tol_pass1_ = std::getenv("DLCO_EIG_TOL_PASS1") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS1")) : 0.85f;  // ... and of the first
-    float tol_pass2_ = std::getenv("DLCO_EIG_TOL_PASS2") ? (float)std::atof(std::getenv("DLCO_EIG_TOL_PASS2")) : 0.5f;   // see update(): tolerance factor of the passes after the first
+    float tol_pass2_ = 0.5f;            // see update(): tolerance factor of the passes after the first
     double panel_amp_ = 1e5;         // largest filter-amplification ratio inside one orthonormalisation panel
     bool debug_ = std::getenv("DLCO_EIG_DEBUG") != nullptr;
     bool guard_stop_ = std::getenv("DLCO_JACOBI_ALL_PAIRS") == nullptr;       // see update(): guard-guard pairs do not prolong Jacobi
