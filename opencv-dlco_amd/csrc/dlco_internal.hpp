@@ -314,9 +314,18 @@ void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *L
 // n floats -> pinned host memory, then *flag_host = seq with system-scope release (the host polls flag_host)
 void publish_block(const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
                    const int *extra_dev = nullptr, int *extra_host = nullptr);   // extra: one device int copied along
+// What the residual kernel may emit on the way (see residual_publish_kernel): the rows of W of the pass it closes
+struct ResidualEmit {
+    float *W = nullptr;
+    long ldw = 0;
+    float mu = 0.f, cscale = 0.f;
+    float *wscale = nullptr;         // scale row i of the block went out with (1 for the rows behind the nw kept ones)
+    bool guards = false;             // also write the rows with theta <= mu, unscaled and in place
+};
 void residual_norms_publish(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res, unsigned *ticket,
                             const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
-                            const int *extra_dev = nullptr, int *extra_host = nullptr);
+                            const int *extra_dev = nullptr, int *extra_host = nullptr, const ResidualEmit *emit = nullptr,
+                            bool *emitted = nullptr);
 void residual_norms(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res,
                     hipStream_t s);
 void row_normalize(float *X, long ld, int m, int F, hipStream_t s, float min_norm = 0.f);

@@ -422,6 +422,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
     const float tol = cold_ ? 0.25f * tol_ : tol_;
     cold_ = false;
     bool conv = false, cheap_done = false;
+    bool w_emitted = false;          // the last pass's residual kernel has written W (all rows of that pass's block, scales too)
     int nw = 0, it = 0;
     int n_ritz = have_theta_ ? m_ : 0;        // leading rows that are Ritz vectors with a known theta
     std::vector<int> panel_ends;
@@ -592,6 +593,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         }
         float *Qn = pick({Qo, Yb});
         float *Yn = pick({Qo, Yb, Qn});
+        w_emitted = false;
         const size_t blk = (size_t)2 * (cap_ + 8) + 1;               // evals | res | sweeps in one copy
         // (second attempt: only after the multi-workgroup Jacobi gave up at its grid barrier - T, Qo and Yb are untouched
         // by a failed attempt, the m x m problem is then solved again by the single-workgroup kernel)
@@ -609,8 +611,12 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
             const unsigned seq = ++publish_seq_;
             int *extra_host = reinterpret_cast<int *>(pin_ + pin_floats_ - 32);
             // (the residual kernel's last workgroup publishes: one launch)
+            // (the kernel also writes this pass's rows of W, guard rows and scales included: if the pass is the update's last,
+            // W is already where it belongs)
+            ResidualEmit em;
+            em.W = W; em.ldw = F_; em.mu = mu; em.cscale = cscale; em.wscale = wscale_.p; em.guards = emit_guards_;
             residual_norms_publish(Q_, Y_, F_, evals_.p, m_, F_, res_.p, reinterpret_cast<unsigned *>(sweeps_dev_ + 4), ritz_block_.p, pin_,
-                                   (int)blk, flag, seq, s_, extra_dev_, extra_host);
+                                   (int)blk, flag, seq, s_, extra_dev_, extra_host, &em, &w_emitted);
             const auto t0 = std::chrono::steady_clock::now();
             bool seen = false;
             for (long spins = 0;; spins++) {
@@ -745,7 +751,7 @@ int EigTracker::update(const float *G, float mu, float cscale, float *W, double 
         if (theta_dev_valid_) {
             // the Ritz values are still on the device in the order of the rows of Q: scale and reverse there
             const bool ext = emit_guards_ && y_ok_ && m_ > nw;
-            emit_w_rows(W, F_, Q_, F_, evals_.p, nw, mu, cscale, F_, s_, ext ? m_ : 0, ext ? wscale_.p : nullptr);
+            if (!w_emitted) emit_w_rows(W, F_, Q_, F_, evals_.p, nw, mu, cscale, F_, s_, ext ? m_ : 0, ext ? wscale_.p : nullptr);
             if (ext) { wext_rows_ = m_; wext_nw_ = nw; }
         } else {
             h_sc_.resize(nw);

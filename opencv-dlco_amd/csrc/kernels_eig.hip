@@ -334,16 +334,41 @@ __global__ __launch_bounds__(256) void publish_block_kernel(const float *src, fl
 // residual_kernel and publish_block_kernel in one launch: the workgroup that finishes LAST (a ticket counter, left at zero
 // again) copies the block - which holds the residuals the other workgroups have just written, hence the agent-scope
 // release / acquire pair around the ticket and the agent-scope loads - and raises the sequence number.
+// em.W != nullptr: the workgroup of row i also writes that row of W - W[nw-1-i] = sqrt(cscale (theta_i - mu)) * x_i for the nw rows
+// with theta > mu (ascending order and scaling of src/pj-learn.cpp:480-487; the arithmetic of emit_w_kernel, bit for bit), the
+// rows behind them unscaled in place when em.guards - and the scale into em.wscale: the row is in flight anyway, and the pass that
+// turns out to be the last one of an update has then emitted W without a launch of its own (an earlier pass's rows are simply
+// written over).
 __global__ __launch_bounds__(256) void residual_publish_kernel(const float *X, const float *Y, long ld, const float *theta, int m, int F,
                                                                float *res, unsigned *ticket, const float *src, float *dst_host, int n,
-                                                               unsigned *flag_host, unsigned seq, const int *extra_dev, int *extra_host)
+                                                               unsigned *flag_host, unsigned seq, const int *extra_dev, int *extra_host,
+                                                               ResidualEmit em)
 {
     __shared__ float part[4];
     __shared__ int last;
+    __shared__ int cnt[4];
     const int i = blockIdx.x;
     const float th = theta[i];
     float s = 0.f;
-    if ((F & 3) == 0 && (ld & 3) == 0) {
+    if (em.W && (F & 3) == 0 && (ld & 3) == 0 && (em.ldw & 3) == 0) {
+        int c = 0;
+        for (int k = threadIdx.x; k < m; k += blockDim.x) c += theta[k] > em.mu ? 1 : 0;
+        c = (int)wsum((float)c);                                  // m <= 4096: exact in fp32
+        if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        const int nw = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        const bool mine = i < nw || em.guards;
+        const float sc = i < nw ? sqrtf(em.cscale * (th - em.mu)) : 1.0f;
+        f32x4 *w4 = reinterpret_cast<f32x4 *>(em.W + (long)(i < nw ? nw - 1 - i : i) * em.ldw);
+        if (em.wscale && threadIdx.x == 0) em.wscale[i] = sc;
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(Y + (long)i * ld), *x4 = reinterpret_cast<const f32x4 *>(X + (long)i * ld);
+        for (int f = threadIdx.x; f < F / 4; f += blockDim.x) {
+            const f32x4 x = x4[f];
+            const f32x4 d = y4[f] - th * x;
+            s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+            if (mine) { f32x4 v = x; v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc; w4[f] = v; }
+        }
+    } else if ((F & 3) == 0 && (ld & 3) == 0) {
         const f32x4 *y4 = reinterpret_cast<const f32x4 *>(Y + (long)i * ld), *x4 = reinterpret_cast<const f32x4 *>(X + (long)i * ld);
         for (int f = threadIdx.x; f < F / 4; f += blockDim.x) {
             const f32x4 d = y4[f] - th * x4[f];
@@ -376,11 +401,14 @@ __global__ __launch_bounds__(256) void residual_publish_kernel(const float *X, c
 
 void residual_norms_publish(const float *X, const float *Y, long ld, const float *theta, int m, int F, float *res, unsigned *ticket,
                             const float *src, float *dst_host, int n, unsigned *flag_host, unsigned seq, hipStream_t s,
-                            const int *extra_dev, int *extra_host)
+                            const int *extra_dev, int *extra_host, const ResidualEmit *emit, bool *emitted)
 {
     DLCO_CHECK(m > 0, -2, "residual_norms_publish: empty block");
+    ResidualEmit em;
+    if (emit && emit->W && (F & 3) == 0 && (ld & 3) == 0 && (emit->ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(emit->W) & 15) == 0) em = *emit;
+    if (emitted) *emitted = em.W != nullptr;
     hipLaunchKernelGGL(residual_publish_kernel, dim3(m), dim3(256), 0, s, X, Y, ld, theta, m, F, res, ticket, src, dst_host, n, flag_host,
-                       seq, extra_dev, extra_host);
+                       seq, extra_dev, extra_host, em);
     DLCO_HIP(hipGetLastError());
 }
 
