@@ -4,9 +4,9 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rows = list(csv.DictReader(open(f)))
 syrk = [r for r in rows if 'syrk_split_rows' in r['Kernel_Name'] or 'syrk_round_rows' in r['Kernel_Name']]      # first kernel of a step's gradient
 start = int(syrk[-nsteps]['Start_Timestamp'])
-# the timed region ends with the last step's W emission; what follows (the LogStep block that
-# bench.py runs after timing) is not part of it
-emit = [r for r in rows if 'emit_w' in r['Kernel_Name']]
+# the region ends with the last step's residual / publish kernel (which also emits W; `emit_w_kernel` only on the
+# host-ordered path); what follows (the LogStep block that bench.py runs after timing) is not part of it
+emit = [r for r in rows if 'emit_w' in r['Kernel_Name'] or 'residual_publish' in r['Kernel_Name']]
 t1 = int(emit[-1]['End_Timestamp']) if emit else max(int(r['End_Timestamp']) for r in rows)
 rows = [r for r in rows if int(r['Start_Timestamp']) <= t1]
 agg = collections.defaultdict(lambda: [0, 0])
