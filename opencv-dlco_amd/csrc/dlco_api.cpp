@@ -306,7 +306,8 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
             return;
         }
     }
-    const int bm = rp <= 128 ? 64 : 128, bn = n <= 64 ? 64 : 128;    // (a 96-row block: two 64-row tiles or one of 128 measured the same, 25 us)
+    const int bm = rp <= 128 ? 64 : 128;     // (a 96-row block: two 64-row tiles or one of 128 measured the same, 25 us;
+    const int bn = (n <= 64 || bm == 64) ? 64 : 128;                                                         //  64-column tiles as well: 19 us)
     const long tiles = (long)((rp + bm - 1) / bm) * ((n + bn - 1) / bn);
     long split = std::max(1L, std::min((512 + tiles - 1) / tiles, (long)c->F / 128));
     const size_t need = (size_t)(split + 1) * rp * n;
@@ -320,6 +321,7 @@ void project_few(dlco_ctx *c, const int32_t *ids_dev, int n, const float *Wd, in
     g.C = proj; g.ldc = n;
     g.split_k = (int)split; g.slab = c->proj_slab.p;
     g.small_m_tiles = bm == 64;
+    g.small_n_tiles = bn == 64;
     c->prof.begin(PROF_PROJECT);
     gemm_f32(g, c->stream);                                      // slabs summed in slice order: deterministic
     sqdist_from_proj(proj, 1, r, n, n, out_dev, c->stream);

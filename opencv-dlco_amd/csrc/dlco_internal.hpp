@@ -151,7 +151,8 @@ struct GemmArgs {
     int *split_out = nullptr;           // receives the number of K slices actually used
     const float *B2 = nullptr;          // twin product in the same launch: C2 = alpha * A * B2 (+ the same epilogue terms), B2 laid
     float *C2 = nullptr;                // out like B; needs split_k == 1
-    bool small_m_tiles = false;         // 64-row tiles whatever M (a 96-row operand: two short tiles run faster than one 128-row tile, measured)
+    bool small_m_tiles = false;         // 64-row tiles whatever M ...
+    bool small_n_tiles = false;         // ... and 64-column tiles whatever N: the 96 x 400 batch projection fills 64 x 64 tiles to 67 %, 64 x 128 ones to 58 % (-6 us)
 };
 
 void gemm_f32(const GemmArgs &a, hipStream_t s);

@@ -506,7 +506,7 @@ void gemm_f32(const GemmArgs &a, hipStream_t s)
     }
     // tile choice: the small dimension decides; a launch that would leave most of the 256 CUs
     // without a workgroup takes 64-wide tiles instead (the tracker's m x F x m products)
-    bool small_m = a.M <= 64 || a.small_m_tiles, small_n = a.N <= 64;
+    bool small_m = a.M <= 64 || a.small_m_tiles, small_n = a.N <= 64 || a.small_n_tiles;
     auto n_wg = [&](bool sm, bool sn) {
         return (long)((a.M + (sm ? 63 : 127)) / (sm ? 64 : 128)) * ((a.N + (sn ? 63 : 127)) / (sn ? 64 : 128)) * split;
     };
