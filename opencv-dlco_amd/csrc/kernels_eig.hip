@@ -283,8 +283,8 @@ __global__ __launch_bounds__(C2_T) void chol_inv2_kernel(const float *M, long ld
     block(std::integral_constant<int, 0>{});
     block(std::integral_constant<int, 1>{});
     block(std::integral_constant<int, 2>{});
-    block(std::integral_constant<int, 3>{});
-    if (NBM > 4) block(std::integral_constant<int, NBM - 1>{});
+    if constexpr (NBM > 3) block(std::integral_constant<int, 3>{});
+    if constexpr (NBM > 4) block(std::integral_constant<int, NBM - 1>{});
     __syncthreads();
     // Linv = D^-1/2 U^-1 (lower triangular); dead rows and the padding are zero
 #pragma unroll
@@ -314,7 +314,8 @@ static void launch_chol_inv2(const float *M, long ldm, int n, float rel_thresh, 
 void chol_inverse128(const float *M, long ldm, int n, float rel_thresh, float *Linv, long ldl, int *dead, hipStream_t s)
 {
     DLCO_CHECK(n >= 1 && n <= CHOL_INV_MAX_N, -2, "chol_inverse128: n out of range");
-    if (n <= 128) launch_chol_inv2<4>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
+    if (n <= 96) launch_chol_inv2<3>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);      // (the steady-state block: 18 matrix registers per thread instead of 32: 44.2 -> 39.7 us at n = 96)
+    else if (n <= 128) launch_chol_inv2<4>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
     else launch_chol_inv2<5>(M, ldm, n, rel_thresh, Linv, ldl, dead, s);
     DLCO_HIP(hipGetLastError());
 }
